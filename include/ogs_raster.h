@@ -1,0 +1,161 @@
+/*
+ * ogs_raster.h -- C ABI of the MI355X-native differentiable Gaussian tile rasterizer.
+ *
+ * This is the drop-in boundary for the native half of the reference's rasterizer package
+ * `ashawkey_diff_gaussian_rasterization` (imported at
+ * /root/reference/gaussian_renderer/__init__.py:15 and utils/sam_refinement_utils.py:21; its
+ * C++/CUDA source is NOT vendored, see .MISSING_LARGE_BLOBS:1).  The entry points below are what
+ * that package's Python side binds as `_C.rasterize_gaussians`, `_C.rasterize_gaussians_backward`
+ * and `_C.mark_visible`, restated as plain C: raw device pointers,
+ * sizes and a HIP stream handle -- no torch types.  The Python facade
+ * (opengaussian_amd/rasterizer.py) binds them with ctypes; INTEGRATION.md shows the stub.
+ *
+ * All pointers are DEVICE pointers to contiguous fp32 / int32 data unless stated otherwise.
+ * `stream` is a hipStream_t passed as void* (0 = the null stream).  Every function returns
+ * OGS_OK (0) or a negative OGS_ERR_* code; ogs_last_error() returns a static description.
+ * Inputs are borrowed and never written.
+ *
+ * Forward is split in two calls because the size of the per-(Gaussian,tile) list
+ * (`num_rendered`) is only known after the geometry phase:
+ *
+ *   ogs_raster_forward_geometry()  preprocess -> depth sort -> scan      (A.1, first half of A.2)
+ *        -> host learns num_rendered, allocates point_list / binning scratch
+ *   ogs_raster_forward_render()    duplicate -> tile sort -> ranges -> blend   (A.2, A.3)
+ *
+ * Replaces the single upstream call `rasterize_gaussians(bg, means3D, colors, opacity, scales,
+ * rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, sh,
+ * degree, campos, prefiltered, debug)` used through GaussianRasterizer.forward at
+ * gaussian_renderer/__init__.py:104-112,129-163,203-225,327-345.
+ */
+#ifndef OGS_RASTER_H
+#define OGS_RASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OGS_OK 0
+#define OGS_ERR_INVALID_ARG (-1)
+#define OGS_ERR_HIP (-2)
+#define OGS_ERR_UNSUPPORTED (-3)
+#define OGS_ERR_SCRATCH_TOO_SMALL (-4)
+
+#define OGS_TILE 16            /* BLOCK_X = BLOCK_Y = 16 */
+#define OGS_MAX_CHANNELS 12    /* blended feature channels per pass: 3 (facade), 6, 9, 12 (fused) */
+
+/* Arguments of one forward pass.  Mirrors the argument list of the reference's
+ * rasterize_gaussians (see file header); `C` generalises its NUM_CHANNELS=3. */
+typedef struct OgsRasterFwdArgs {
+    int32_t P;               /* number of Gaussians */
+    int32_t W, H;            /* image size in pixels */
+    int32_t C;               /* blended channels (3 for the drop-in facade) */
+    int32_t sh_degree;       /* active SH degree 0..3 (used when shs != NULL) */
+    int32_t sh_coeffs;       /* M: coefficients per Gaussian stored in shs ([P,M,3]) */
+    float tanfovx, tanfovy;
+    float scale_modifier;
+    int32_t prefiltered;     /* accepted for API parity; unused (as upstream) */
+    int32_t debug;           /* !=0: synchronise + check after every kernel */
+    const float* bg;             /* [C] */
+    const float* means3D;        /* [P,3] */
+    const float* colors_precomp; /* [P,C] or NULL */
+    const float* shs;            /* [P,M,3] or NULL (requires C == 3) */
+    const float* opacities;      /* [P] */
+    const float* scales;         /* [P,3] or NULL */
+    const float* rotations;      /* [P,4] or NULL */
+    const float* cov3D_precomp;  /* [P,6] or NULL */
+    const float* viewmatrix;     /* [16] row-major W2C^T (scene/cameras.py:71) */
+    const float* projmatrix;     /* [16] row-major W2C^T @ P^T (scene/cameras.py:76) */
+    const float* campos;         /* [3] */
+    float* out_color;            /* [C,H,W] */
+    float* out_depth;            /* [1,H,W] */
+    float* out_alpha;            /* [1,H,W] */
+    int32_t* radii;              /* [P] */
+    void* geom_buffer;           /* ogs_raster_geom_bytes(P, C): kept until backward */
+    void* geom_tmp;              /* ogs_raster_geom_tmp_bytes(P): must live across both forward calls */
+    void* image_buffer;          /* ogs_raster_image_bytes(W, H): kept until backward */
+    uint32_t* point_list;        /* [num_rendered] sorted Gaussian ids: kept until backward (render phase) */
+    void* binning_tmp;           /* ogs_raster_binning_tmp_bytes(num_rendered, W, H) (render phase) */
+} OgsRasterFwdArgs;
+
+/* Arguments of the backward pass.  Mirrors upstream rasterize_gaussians_backward(bg, means3D,
+ * radii, colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix,
+ * tan_fovx, tan_fovy, dL_dcolor, dL_ddepth, dL_dalpha, sh, degree, campos, geomBuffer, R,
+ * binningBuffer, imgBuffer, alpha, debug).  Any output pointer may be NULL to skip that
+ * gradient family (stages 1-2 only need dL_dcolors + dL_dmeans2D). */
+typedef struct OgsRasterBwdArgs {
+    int32_t P, W, H, C, sh_degree, sh_coeffs;
+    float tanfovx, tanfovy, scale_modifier;
+    int32_t debug;
+    int32_t num_rendered;
+    const float* bg;
+    const float* means3D;
+    const float* colors_precomp;
+    const float* shs;
+    const float* opacities;
+    const float* scales;
+    const float* rotations;
+    const float* cov3D_precomp;
+    const float* viewmatrix;
+    const float* projmatrix;
+    const float* campos;
+    const int32_t* radii;        /* [P] from forward */
+    const float* out_alpha;      /* [1,H,W] from forward */
+    const float* dL_dcolor;      /* [C,H,W] */
+    const float* dL_ddepth;      /* [1,H,W] or NULL (= zeros) */
+    const float* dL_dalpha;      /* [1,H,W] or NULL (= zeros) */
+    const void* geom_buffer;
+    const void* image_buffer;
+    const uint32_t* point_list;
+    void* bwd_tmp;               /* ogs_raster_backward_tmp_bytes(P): zeroed by the call */
+    float* dL_dmeans2D;          /* [P,3] (x,y in NDC units: pixel gradient * 0.5*W / 0.5*H; z = 0) */
+    float* dL_dcolors;           /* [P,C]   (when colors_precomp was the input) */
+    float* dL_dopacity;          /* [P] */
+    float* dL_dmeans3D;          /* [P,3] */
+    float* dL_dcov3D;            /* [P,6]   (when cov3D_precomp was the input) */
+    float* dL_dsh;               /* [P,M,3] (when shs was the input) */
+    float* dL_dscales;           /* [P,3] */
+    float* dL_drotations;        /* [P,4] */
+} OgsRasterBwdArgs;
+
+int ogs_version(void);
+const char* ogs_last_error(void);
+
+size_t ogs_raster_geom_bytes(int32_t P, int32_t C);
+size_t ogs_raster_geom_tmp_bytes(int32_t P);
+size_t ogs_raster_image_bytes(int32_t W, int32_t H);
+size_t ogs_raster_binning_tmp_bytes(int64_t num_rendered, int32_t W, int32_t H);
+size_t ogs_raster_backward_tmp_bytes(int32_t P);
+
+/* Phase 1: fills radii + geom_buffer, leaves the depth order and tile offsets in geom_tmp, writes
+ * num_rendered to *num_rendered_host (host memory) and returns after the stream has finished it
+ * (the same blocking read-back the reference performs once per forward). */
+int ogs_raster_forward_geometry(const OgsRasterFwdArgs* args, void* stream, int64_t* num_rendered_host);
+
+/* Phase 2: needs args->point_list / args->binning_tmp sized for num_rendered.  Asynchronous. */
+int ogs_raster_forward_render(const OgsRasterFwdArgs* args, int64_t num_rendered, void* stream);
+
+/* Backward.  Asynchronous on `stream`. */
+int ogs_raster_backward(const OgsRasterBwdArgs* args, void* stream);
+
+/* Replaces upstream mark_visible(means3D, viewmatrix, projmatrix) -> bool[P]: near-plane test
+ * p_view.z > 0.2 (SURVEY.md section 2.1 `checkFrustum`). `present` is uint8[P]. */
+int ogs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     uint8_t* present, void* stream);
+
+/* Test/diagnostic export of the binning state the reference keeps in its binningBuffer /
+ * imgBuffer: the sorted 64-bit keys (tile << 32 | float_bits(depth)) [num_rendered], the per-tile
+ * ranges [T,2] and n_contrib [H,W].  Any output may be NULL. */
+int ogs_raster_export_binning(const OgsRasterFwdArgs* args, int64_t num_rendered, uint64_t* keys_out,
+                              uint32_t* ranges_out, uint32_t* n_contrib_out, void* stream);
+
+/* Test hook, not part of the reference boundary: runs the wave64 16-slot transposed reduction of the
+ * backward blend on in[64][16]; out[lane] = sum over lanes of slot (lane >> 2). */
+int ogs_selftest_wave_fold16(const float* in, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OGS_RASTER_H */

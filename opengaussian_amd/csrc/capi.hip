@@ -1,0 +1,181 @@
+// extern "C" entry points of libogs_hip.so (declared in include/ogs_raster.h).  Host-side
+// orchestration only: argument validation, scratch carving, kernel sequencing on the caller's stream.
+#include <stdarg.h>
+#include <string.h>
+
+#include "ogs_common.h"
+
+namespace ogs {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static int bit_length(uint32_t v) {
+    int n = 0;
+    while (v) { ++n; v >>= 1; }
+    return n;
+}
+
+static int validate_fwd(const OgsRasterFwdArgs* a) {
+    if (!a) { set_error("args == NULL"); return OGS_ERR_INVALID_ARG; }
+    if (a->P < 0 || a->W <= 0 || a->H <= 0) { set_error("bad sizes P=%d W=%d H=%d", a->P, a->W, a->H); return OGS_ERR_INVALID_ARG; }
+    if (a->C != 3 && a->C != 6 && a->C != 9 && a->C != 12) { set_error("C=%d unsupported (3, 6, 9, 12)", a->C); return OGS_ERR_UNSUPPORTED; }
+    if ((a->shs != nullptr) == (a->colors_precomp != nullptr)) {
+        set_error("provide exactly one of shs / colors_precomp"); return OGS_ERR_INVALID_ARG;
+    }
+    const bool sr = a->scales != nullptr && a->rotations != nullptr;
+    if (sr == (a->cov3D_precomp != nullptr) || (a->scales != nullptr) != (a->rotations != nullptr)) {
+        set_error("provide exactly one of (scales, rotations) / cov3D_precomp"); return OGS_ERR_INVALID_ARG;
+    }
+    if (a->shs) {
+        if (a->C != 3) { set_error("SH colours need C == 3"); return OGS_ERR_INVALID_ARG; }
+        if (a->sh_degree < 0 || a->sh_degree > 3 || a->sh_coeffs < (a->sh_degree + 1) * (a->sh_degree + 1)) {
+            set_error("sh_degree=%d needs >= %d coefficients, got %d", a->sh_degree, (a->sh_degree + 1) * (a->sh_degree + 1), a->sh_coeffs);
+            return OGS_ERR_INVALID_ARG;
+        }
+    }
+    if (!a->bg || !a->viewmatrix || !a->projmatrix || !a->campos || !a->out_color || !a->out_depth || !a->out_alpha ||
+        !a->image_buffer) { set_error("NULL required pointer"); return OGS_ERR_INVALID_ARG; }
+    if (a->P > 0 && (!a->means3D || !a->opacities || !a->radii || !a->geom_buffer || !a->geom_tmp)) {
+        set_error("NULL required per-Gaussian pointer"); return OGS_ERR_INVALID_ARG;
+    }
+    return OGS_OK;
+}
+
+}  // namespace ogs
+
+using namespace ogs;
+
+extern "C" {
+
+int ogs_version(void) { return 100; }
+const char* ogs_last_error(void) { return g_err; }
+
+size_t ogs_raster_geom_bytes(int32_t P, int32_t C) { return GeomState::bytes(P > 0 ? P : 1, C); }
+size_t ogs_raster_geom_tmp_bytes(int32_t P) { return GeomTmp::bytes(P > 0 ? P : 1); }
+size_t ogs_raster_image_bytes(int32_t W, int32_t H) { return ImageState::bytes(W, H); }
+size_t ogs_raster_binning_tmp_bytes(int64_t D, int32_t, int32_t) { return BinTmp::bytes(D > 0 ? D : 1); }
+size_t ogs_raster_backward_tmp_bytes(int32_t P) { return align_up((size_t)(P > 0 ? P : 1) * 16 * sizeof(float)); }
+
+int ogs_raster_forward_geometry(const OgsRasterFwdArgs* a, void* stream_, int64_t* num_rendered_host) {
+    int rc = validate_fwd(a);
+    if (rc != OGS_OK) return rc;
+    if (!num_rendered_host) { set_error("num_rendered_host == NULL"); return OGS_ERR_INVALID_ARG; }
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    *num_rendered_host = 0;
+    if (a->P == 0) return OGS_OK;
+    const GeomState gs = GeomState::carve(a->geom_buffer, a->P, a->C);
+    const GeomTmp gt = GeomTmp::carve(a->geom_tmp, a->P);
+    rc = launch_preprocess(*a, gs, gt, s);
+    if (rc != OGS_OK) return rc;
+    // depth sort of the P Gaussians: 4 x 8-bit stable passes, ends in keys[0]/order[0]
+    for (int pass = 0; pass < 4; ++pass) {
+        const int in = pass & 1, out = in ^ 1;
+        rc = radix_pass(gt.keys[in], gt.order[in], gt.keys[out], gt.order[out], a->P, 8 * pass, 8, gt.sort_tmp, s, a->debug);
+        if (rc != OGS_OK) return rc;
+    }
+    // offsets[r] = exclusive scan of tiles_touched in depth order; total = num_rendered
+    rc = exclusive_scan_u32(gt.tiles_touched, gt.order[0], gt.offsets, a->P, gt.num_rendered, gt.sort_tmp, s, a->debug);
+    if (rc != OGS_OK) return rc;
+    uint32_t d = 0;
+    OGS_HIP_CHECK(hipMemcpyAsync(&d, gt.num_rendered, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    OGS_HIP_CHECK(hipStreamSynchronize(s));
+    *num_rendered_host = (int64_t)d;
+    return OGS_OK;
+}
+
+int ogs_raster_forward_render(const OgsRasterFwdArgs* a, int64_t D, void* stream_) {
+    int rc = validate_fwd(a);
+    if (rc != OGS_OK) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    const ImageState is = ImageState::carve(a->image_buffer, a->W, a->H);
+    const int gx = (a->W + kTile - 1) / kTile, gy = (a->H + kTile - 1) / kTile;
+    const int tiles = gx * gy;
+    const GeomState gs = GeomState::carve(a->geom_buffer, a->P > 0 ? a->P : 1, a->C);
+    if (D > 0) {
+        if (!a->point_list || !a->binning_tmp) { set_error("point_list / binning_tmp == NULL with num_rendered=%lld", (long long)D); return OGS_ERR_INVALID_ARG; }
+        if (D >= (1ll << 31)) { set_error("num_rendered=%lld exceeds 2^31", (long long)D); return OGS_ERR_UNSUPPORTED; }
+        const GeomTmp gt = GeomTmp::carve(a->geom_tmp, a->P);
+        const BinTmp bt = BinTmp::carve(a->binning_tmp, D);
+        const int bits = bit_length((uint32_t)(tiles - 1));
+        const int passes = bits == 0 ? 1 : (bits + 7) / 8;
+        const int per = bits == 0 ? 1 : (bits + passes - 1) / passes;
+        // value ping-pong is arranged so that the LAST pass writes args->point_list
+        uint32_t* vbuf[2];
+        vbuf[passes & 1] = a->point_list;        // buffer index after `passes` flips from 0
+        vbuf[(passes & 1) ^ 1] = bt.vals;
+        rc = launch_duplicate(*a, gs, gt, bt.tile_keys[0], vbuf[0], s);
+        if (rc != OGS_OK) return rc;
+        for (int p = 0; p < passes; ++p) {
+            const int in = p & 1, out = in ^ 1;
+            const int shift = p * per;
+            const int nb = (p == passes - 1) ? (bits == 0 ? 1 : bits - shift) : per;
+            rc = radix_pass(bt.tile_keys[in], vbuf[in], bt.tile_keys[out], vbuf[out], D, shift, nb, bt.sort_tmp, s, a->debug);
+            if (rc != OGS_OK) return rc;
+        }
+        rc = launch_tile_ranges(bt.tile_keys[passes & 1], D, is.ranges, tiles, s, a->debug);
+        if (rc != OGS_OK) return rc;
+    } else {
+        OGS_HIP_CHECK(hipMemsetAsync(is.ranges, 0, (size_t)tiles * sizeof(uint2), s));
+    }
+    return launch_blend_forward(*a, gs, is, s);
+}
+
+int ogs_raster_backward(const OgsRasterBwdArgs* a, void* stream_) {
+    if (!a) { set_error("args == NULL"); return OGS_ERR_INVALID_ARG; }
+    if (a->C != 3 && a->C != 6 && a->C != 9) { set_error("backward: C=%d unsupported (3, 6, 9)", a->C); return OGS_ERR_UNSUPPORTED; }
+    if (a->P == 0) return OGS_OK;
+    if (!a->dL_dcolor || !a->geom_buffer || !a->image_buffer || !a->bwd_tmp || !a->radii || !a->out_alpha || !a->bg ||
+        !a->means3D || !a->viewmatrix || !a->projmatrix || !a->campos) {
+        set_error("backward: NULL required pointer"); return OGS_ERR_INVALID_ARG;
+    }
+    if (a->num_rendered > 0 && !a->point_list) { set_error("backward: point_list == NULL"); return OGS_ERR_INVALID_ARG; }
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    const GeomState gs = GeomState::carve(const_cast<void*>(a->geom_buffer), a->P, a->C);
+    const ImageState is = ImageState::carve(const_cast<void*>(a->image_buffer), a->W, a->H);
+    float* grad_rec = static_cast<float*>(a->bwd_tmp);
+    OGS_HIP_CHECK(hipMemsetAsync(grad_rec, 0, (size_t)a->P * grad_stride(a->C) * sizeof(float), s));
+    int rc = launch_blend_backward(*a, gs, is, grad_rec, s);
+    if (rc != OGS_OK) return rc;
+    return launch_preprocess_backward(*a, gs, grad_rec, s);
+}
+
+int ogs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float*, uint8_t* present,
+                     void* stream_) {
+    if (P == 0) return OGS_OK;
+    if (!means3D || !viewmatrix || !present) { set_error("mark_visible: NULL pointer"); return OGS_ERR_INVALID_ARG; }
+    return launch_mark_visible(P, means3D, viewmatrix, present, static_cast<hipStream_t>(stream_));
+}
+
+/* test hook (not part of the reference boundary): the wave64 16-slot transposed reduction used by the
+ * backward blend.  in: [64][16] floats, out: [64]; out[lane] must equal sum_l in[l][lane>>2]. */
+int ogs_selftest_wave_fold16(const float* in, float* out, void* stream_) {
+    if (!in || !out) { set_error("selftest: NULL pointer"); return OGS_ERR_INVALID_ARG; }
+    return launch_wave_fold16_test(in, out, static_cast<hipStream_t>(stream_));
+}
+
+int ogs_raster_export_binning(const OgsRasterFwdArgs* a, int64_t D, uint64_t* keys_out, uint32_t* ranges_out,
+                              uint32_t* n_contrib_out, void* stream_) {
+    if (!a) { set_error("args == NULL"); return OGS_ERR_INVALID_ARG; }
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    const ImageState is = ImageState::carve(a->image_buffer, a->W, a->H);
+    const int gx = (a->W + kTile - 1) / kTile, gy = (a->H + kTile - 1) / kTile;
+    if (keys_out && D > 0) {
+        const GeomState gs = GeomState::carve(a->geom_buffer, a->P, a->C);
+        int rc = launch_export_keys(is.ranges, gx * gy, a->point_list, gs.rec, rec_vec4(a->C), keys_out, s);
+        if (rc != OGS_OK) return rc;
+    }
+    if (ranges_out)
+        OGS_HIP_CHECK(hipMemcpyAsync(ranges_out, is.ranges, (size_t)gx * gy * sizeof(uint2), hipMemcpyDeviceToDevice, s));
+    if (n_contrib_out)
+        OGS_HIP_CHECK(hipMemcpyAsync(n_contrib_out, is.n_contrib, (size_t)a->W * a->H * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    return OGS_OK;
+}
+
+}  // extern "C"

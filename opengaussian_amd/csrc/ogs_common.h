@@ -1,0 +1,190 @@
+// Shared declarations for the gfx950 rasterizer / k-means kernels (internal; the public C ABI is
+// include/ogs_raster.h and include/ogs_kmeans.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <stdio.h>
+
+#include "../../include/ogs_raster.h"
+
+namespace ogs {
+
+constexpr int kTile = OGS_TILE;      // 16x16 pixel tiles
+constexpr int kBlock = 256;          // 4 wave64 per workgroup everywhere
+constexpr int kWave = 64;
+
+// ---- error plumbing -------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+
+#define OGS_HIP_CHECK(expr)                                                              \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            ogs::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return OGS_ERR_HIP;                                                          \
+        }                                                                                \
+    } while (0)
+
+// After a kernel launch: always catch launch errors; with debug also synchronise (the reference's
+// debug=True behaviour, SURVEY.md section 8(b) "Errors").
+#define OGS_LAUNCH_CHECK(debug, stream)                                                  \
+    do {                                                                                 \
+        OGS_HIP_CHECK(hipGetLastError());                                                \
+        if (debug) OGS_HIP_CHECK(hipStreamSynchronize(stream));                          \
+    } while (0)
+
+// ---- scratch carving ------------------------------------------------------------------------
+constexpr size_t kAlign = 256;
+inline size_t align_up(size_t v, size_t a = kAlign) { return (v + a - 1) / a * a; }
+
+struct Carver {
+    char* base;
+    size_t off = 0;
+    explicit Carver(void* p) : base(static_cast<char*>(p)) {}
+    template <typename T>
+    T* take(size_t n) {
+        T* r = reinterpret_cast<T*>(base ? base + off : nullptr);
+        off = align_up(off + n * sizeof(T));
+        return r;
+    }
+};
+
+// ---- per-Gaussian forward record ("rec") ------------------------------------------------------
+// One contiguous, 16-byte aligned record per Gaussian, written by preprocess and gathered by the
+// blend kernels with float4 loads:
+//   f4[0] = { px, py, depth, bits(radius) }     pixel centre, view depth, int radius
+//   f4[1] = { conic A, B, C, opacity }
+//   f4[2..] = C blended feature channels, zero padded to a multiple of 4
+__host__ __device__ constexpr int rec_vec4(int C) { return 2 + (C + 3) / 4; }   // float4 per record
+
+// Per-Gaussian gradient record accumulated by the backward blend (64 B = one atomic segment):
+//   [0..C) dL/dfeature, [C] dL/ddepth, [C+1..C+2] dL/dmean2D (NDC scaled), [C+3..C+5] dL/dconic(A,B,C),
+//   [C+6] dL/dopacity ; C <= 9 fits 16 floats, C == 12 uses 32.
+__host__ __device__ constexpr int grad_stride(int C) { return (C + 7 <= 16) ? 16 : 32; }
+
+// ---- geometry scratch layout (shared by forward phases) ------------------------------------------
+struct GeomState {      // kept until backward
+    float4* rec;        // [P * rec_vec4(C)]
+    uint32_t* clamped;  // [P] bit ch set when SH colour channel ch was clamped at 0
+    static GeomState carve(void* p, int P, int C) {
+        Carver c(p);
+        GeomState g;
+        g.rec = c.take<float4>((size_t)P * rec_vec4(C));
+        g.clamped = c.take<uint32_t>(P);
+        return g;
+    }
+    static size_t bytes(int P, int C) {
+        Carver c(nullptr);
+        c.take<float4>((size_t)P * rec_vec4(C));
+        c.take<uint32_t>(P);
+        return c.off;
+    }
+};
+
+struct ImageState {     // kept until backward
+    uint2* ranges;          // [tiles]
+    uint32_t* n_contrib;    // [W*H]
+    static ImageState carve(void* p, int W, int H) {
+        Carver c(p);
+        ImageState s;
+        int tiles = ((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile);
+        s.ranges = c.take<uint2>(tiles);
+        s.n_contrib = c.take<uint32_t>((size_t)W * H);
+        return s;
+    }
+    static size_t bytes(int W, int H) {
+        Carver c(nullptr);
+        int tiles = ((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile);
+        c.take<uint2>(tiles);
+        c.take<uint32_t>((size_t)W * H);
+        return c.off;
+    }
+};
+
+// radix sort / scan (binning.hip) ---------------------------------------------------------------
+constexpr int kSortItems = 16;                         // keys per thread
+constexpr int kSortTile = kBlock * kSortItems;         // 4096 keys per workgroup
+inline int sort_blocks(int64_t n) { return (int)((n + kSortTile - 1) / kSortTile); }
+size_t scan_tmp_bytes(int64_t n);
+size_t sort_tmp_bytes(int64_t n);                      // histogram + scan scratch for one pass
+
+// exclusive prefix sum of n uint32 (in may equal out); if total != nullptr the grand total is
+// written there (device).  `gather` (optional) makes element i = in[gather[i]].
+int exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int64_t n,
+                       uint32_t* total, void* tmp, hipStream_t stream, int debug);
+// One stable LSD pass on bits [shift, shift+bits) of keys_in (bits <= 8).
+int radix_pass(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
+               int64_t n, int shift, int bits, void* tmp, hipStream_t stream, int debug);
+
+struct GeomTmp {        // transient, but must survive from forward_geometry to forward_render
+    uint32_t* tiles_touched;   // [P]
+    uint32_t* keys[2];         // [P] depth bits ping-pong
+    uint32_t* order[2];        // [P] Gaussian ids ping-pong; order[0] holds the depth order at the end
+    uint32_t* offsets;         // [P] exclusive scan of tiles_touched in depth order
+    uint32_t* num_rendered;    // [1]
+    void* sort_tmp;
+    static GeomTmp carve(void* p, int P) {
+        Carver c(p);
+        GeomTmp g;
+        g.tiles_touched = c.take<uint32_t>(P);
+        g.keys[0] = c.take<uint32_t>(P);
+        g.keys[1] = c.take<uint32_t>(P);
+        g.order[0] = c.take<uint32_t>(P);
+        g.order[1] = c.take<uint32_t>(P);
+        g.offsets = c.take<uint32_t>(P);
+        g.num_rendered = c.take<uint32_t>(64);
+        g.sort_tmp = c.take<char>(sort_tmp_bytes(P));
+        return g;
+    }
+    static size_t bytes(int P) {
+        Carver c(nullptr);
+        for (int i = 0; i < 6; ++i) c.take<uint32_t>(P);
+        c.take<uint32_t>(64);
+        c.take<char>(sort_tmp_bytes(P));
+        return c.off;
+    }
+};
+
+struct BinTmp {         // transient, render phase
+    uint32_t* tile_keys[2];    // [D]
+    uint32_t* vals;            // [D] ping buffer (the pong is args->point_list)
+    void* sort_tmp;
+    static BinTmp carve(void* p, int64_t D) {
+        Carver c(p);
+        BinTmp b;
+        b.tile_keys[0] = c.take<uint32_t>(D);
+        b.tile_keys[1] = c.take<uint32_t>(D);
+        b.vals = c.take<uint32_t>(D);
+        b.sort_tmp = c.take<char>(sort_tmp_bytes(D));
+        return b;
+    }
+    static size_t bytes(int64_t D) {
+        Carver c(nullptr);
+        for (int i = 0; i < 3; ++i) c.take<uint32_t>(D);
+        c.take<char>(sort_tmp_bytes(D));
+        return c.off;
+    }
+};
+
+// kernels launched by capi.hip ------------------------------------------------------------------
+int launch_preprocess(const OgsRasterFwdArgs& a, const GeomState& gs, const GeomTmp& gt, hipStream_t s);
+int launch_duplicate(const OgsRasterFwdArgs& a, const GeomState& gs, const GeomTmp& gt, uint32_t* tile_keys,
+                     uint32_t* vals, hipStream_t s);
+int launch_tile_ranges(const uint32_t* tile_keys_sorted, int64_t D, uint2* ranges, int tiles, hipStream_t s,
+                       int debug);
+int launch_blend_forward(const OgsRasterFwdArgs& a, const GeomState& gs, const ImageState& is, hipStream_t s);
+int launch_blend_backward(const OgsRasterBwdArgs& a, const GeomState& gs, const ImageState& is, float* grad_rec,
+                          hipStream_t s);
+int launch_preprocess_backward(const OgsRasterBwdArgs& a, const GeomState& gs, const float* grad_rec,
+                               hipStream_t s);
+int launch_wave_fold16_test(const float* in, float* out, hipStream_t s);
+int launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
+int launch_export_keys(const uint2* ranges, int tiles, const uint32_t* point_list, const float4* rec, int recv4,
+                       uint64_t* keys_out, hipStream_t s);
+
+// ---- tiny device helpers ------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+
+}  // namespace ogs

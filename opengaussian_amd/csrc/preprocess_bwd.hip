@@ -1,0 +1,301 @@
+// Backward per-Gaussian preprocess for gfx950.
+//
+// One thread per Gaussian.  Reads the 64-byte gradient record the backward blend accumulated
+// (4 x float4, coalesced), re-derives the forward intermediates from the original inputs (cheaper than
+// storing cov3D / T / J per Gaussian: 0 extra bytes kept between forward and backward) and writes every
+// requested gradient exactly once -- culled Gaussians get zeros, so no output needs a prior memset.
+// HBM-bound: <= 300 B read, <= 300 B written per Gaussian (SH path dominates with 192 B of dL/dsh).
+#include "ogs_common.h"
+
+namespace ogs {
+
+namespace {
+
+constexpr float kC0 = 0.28209479177387814f;
+constexpr float kC1 = 0.4886025119029199f;
+__device__ constexpr float kC2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                     -1.0925484305920792f, 0.5462742152960396f};
+__device__ constexpr float kC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                     0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                     -0.5900435899266435f};
+
+template <int C>
+__global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
+    int P, int W, int H, int sh_degree, int sh_coeffs, float tanfovx, float tanfovy, float focal_x, float focal_y,
+    float scale_modifier, const float* __restrict__ means3D, const float* __restrict__ shs,
+    const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
+    const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
+    const int32_t* __restrict__ radii, const uint32_t* __restrict__ clamped_in, const float* __restrict__ grad_rec,
+    float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
+    float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
+    float* __restrict__ dL_dscales, float* __restrict__ dL_drotations) {
+    constexpr int GS = grad_stride(C);
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= P) return;
+    const bool vis = radii[idx] > 0;
+
+    float gr[16];
+    {
+        const float4* g4 = reinterpret_cast<const float4*>(grad_rec + (size_t)idx * GS);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float4 t = vis ? g4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+            gr[4 * k] = t.x; gr[4 * k + 1] = t.y; gr[4 * k + 2] = t.z; gr[4 * k + 3] = t.w;
+        }
+    }
+    const float d_depth = gr[C];
+    const float dm2x = gr[C + 1], dm2y = gr[C + 2];
+    const float dconA = gr[C + 3], dconB = gr[C + 4], dconC = gr[C + 5];
+
+    if (dL_dmeans2D) {
+        dL_dmeans2D[3 * idx + 0] = dm2x;
+        dL_dmeans2D[3 * idx + 1] = dm2y;
+        dL_dmeans2D[3 * idx + 2] = 0.f;
+    }
+    if (dL_dopacity) dL_dopacity[idx] = gr[C + 6];
+    if (dL_dcolors) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) dL_dcolors[(size_t)idx * C + c] = gr[c];
+    }
+
+    float dmean[3] = {0.f, 0.f, 0.f};
+    float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dscale[3] = {0.f, 0.f, 0.f};
+    float drot[4] = {0.f, 0.f, 0.f, 0.f};
+
+    const bool need_geom = dL_dmeans3D || dL_dcov3D || dL_dscales || dL_drotations || dL_dsh;
+    if (vis && need_geom) {
+        float V[16], M[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { V[i] = viewmatrix[i]; M[i] = projmatrix[i]; }
+        const float x = means3D[3 * idx], y = means3D[3 * idx + 1], z = means3D[3 * idx + 2];
+
+        // ---- forward intermediates --------------------------------------------------------------
+        float cov[6];
+        float Rm[9] = {0}, sx = 0.f, sy = 0.f, sz = 0.f, qr = 0.f, qx = 0.f, qy = 0.f, qz = 0.f;
+        if (cov3D_precomp) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) cov[i] = cov3D_precomp[6 * idx + i];
+        } else {
+            sx = scale_modifier * scales[3 * idx]; sy = scale_modifier * scales[3 * idx + 1];
+            sz = scale_modifier * scales[3 * idx + 2];
+            const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
+            qr = q.x; qx = q.y; qy = q.z; qz = q.w;
+            Rm[0] = 1.f - 2.f * (qy * qy + qz * qz); Rm[1] = 2.f * (qx * qy - qr * qz); Rm[2] = 2.f * (qx * qz + qr * qy);
+            Rm[3] = 2.f * (qx * qy + qr * qz); Rm[4] = 1.f - 2.f * (qx * qx + qz * qz); Rm[5] = 2.f * (qy * qz - qr * qx);
+            Rm[6] = 2.f * (qx * qz - qr * qy); Rm[7] = 2.f * (qy * qz + qr * qx); Rm[8] = 1.f - 2.f * (qx * qx + qy * qy);
+            const float Mm[9] = {Rm[0] * sx, Rm[1] * sy, Rm[2] * sz, Rm[3] * sx, Rm[4] * sy, Rm[5] * sz,
+                                 Rm[6] * sx, Rm[7] * sy, Rm[8] * sz};
+            cov[0] = Mm[0] * Mm[0] + Mm[1] * Mm[1] + Mm[2] * Mm[2];
+            cov[1] = Mm[0] * Mm[3] + Mm[1] * Mm[4] + Mm[2] * Mm[5];
+            cov[2] = Mm[0] * Mm[6] + Mm[1] * Mm[7] + Mm[2] * Mm[8];
+            cov[3] = Mm[3] * Mm[3] + Mm[4] * Mm[4] + Mm[5] * Mm[5];
+            cov[4] = Mm[3] * Mm[6] + Mm[4] * Mm[7] + Mm[5] * Mm[8];
+            cov[5] = Mm[6] * Mm[6] + Mm[7] * Mm[7] + Mm[8] * Mm[8];
+        }
+        const float pvx = V[0] * x + V[4] * y + V[8] * z + V[12];
+        const float pvy = V[1] * x + V[5] * y + V[9] * z + V[13];
+        const float pvz = V[2] * x + V[6] * y + V[10] * z + V[14];
+        const float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+        const float txtz = pvx / pvz, tytz = pvy / pvz;
+        const float tx = fminf(limx, fmaxf(-limx, txtz)) * pvz;
+        const float ty = fminf(limy, fmaxf(-limy, tytz)) * pvz;
+        const float x_grad_mul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+        const float y_grad_mul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+        const float tz = pvz;
+        const float itz = 1.f / tz, itz2 = itz * itz, itz3 = itz2 * itz;
+        const float J00 = focal_x * itz, J02 = -(focal_x * tx) * itz2;
+        const float J11 = focal_y * itz, J12 = -(focal_y * ty) * itz2;
+        // Wr[i][k] = V[4k+i]
+        const float T0[3] = {J00 * V[0] + J02 * V[2], J00 * V[4] + J02 * V[6], J00 * V[8] + J02 * V[10]};
+        const float T1[3] = {J11 * V[1] + J12 * V[2], J11 * V[5] + J12 * V[6], J11 * V[9] + J12 * V[10]};
+        // S*T0, S*T1 (S symmetric 3x3)
+        const float S0[3] = {cov[0] * T0[0] + cov[1] * T0[1] + cov[2] * T0[2],
+                             cov[1] * T0[0] + cov[3] * T0[1] + cov[4] * T0[2],
+                             cov[2] * T0[0] + cov[4] * T0[1] + cov[5] * T0[2]};
+        const float S1[3] = {cov[0] * T1[0] + cov[1] * T1[1] + cov[2] * T1[2],
+                             cov[1] * T1[0] + cov[3] * T1[1] + cov[4] * T1[2],
+                             cov[2] * T1[0] + cov[4] * T1[1] + cov[5] * T1[2]};
+        const float a = T0[0] * S0[0] + T0[1] * S0[1] + T0[2] * S0[2] + 0.3f;
+        const float b = T0[0] * S1[0] + T0[1] * S1[1] + T0[2] * S1[2];
+        const float c = T1[0] * S1[0] + T1[1] * S1[1] + T1[2] * S1[2] + 0.3f;
+
+        // ---- conic -> cov2D (a,b,c) ------------------------------------------------------------------
+        const float denom = a * c - b * b;
+        const float denom2inv = 1.0f / (denom * denom + 0.0000001f);
+        float da = 0.f, db = 0.f, dc = 0.f;
+        if (denom2inv != 0.f) {
+            da = denom2inv * (-c * c * dconA + 2.f * b * c * dconB + (denom - a * c) * dconC);
+            dc = denom2inv * (-a * a * dconC + 2.f * a * b * dconB + (denom - a * c) * dconA);
+            db = denom2inv * 2.f * (b * c * dconA - (denom + 2.f * b * b) * dconB + a * b * dconC);
+            // ---- cov2D -> cov3D (packed: off-diagonals count both entries) ---------------------------
+            dcov[0] = T0[0] * T0[0] * da + T0[0] * T1[0] * db + T1[0] * T1[0] * dc;
+            dcov[3] = T0[1] * T0[1] * da + T0[1] * T1[1] * db + T1[1] * T1[1] * dc;
+            dcov[5] = T0[2] * T0[2] * da + T0[2] * T1[2] * db + T1[2] * T1[2] * dc;
+            dcov[1] = 2.f * T0[0] * T0[1] * da + (T0[0] * T1[1] + T0[1] * T1[0]) * db + 2.f * T1[0] * T1[1] * dc;
+            dcov[2] = 2.f * T0[0] * T0[2] * da + (T0[0] * T1[2] + T0[2] * T1[0]) * db + 2.f * T1[0] * T1[2] * dc;
+            dcov[4] = 2.f * T0[2] * T0[1] * da + (T0[1] * T1[2] + T0[2] * T1[1]) * db + 2.f * T1[1] * T1[2] * dc;
+        }
+        // ---- cov2D -> T -> J -> t -> mean ------------------------------------------------------------
+        float dT0[3], dT1[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            dT0[k] = 2.f * S0[k] * da + S1[k] * db;
+            dT1[k] = 2.f * S1[k] * dc + S0[k] * db;
+        }
+        const float dJ00 = V[0] * dT0[0] + V[4] * dT0[1] + V[8] * dT0[2];
+        const float dJ02 = V[2] * dT0[0] + V[6] * dT0[1] + V[10] * dT0[2];
+        const float dJ11 = V[1] * dT1[0] + V[5] * dT1[1] + V[9] * dT1[2];
+        const float dJ12 = V[2] * dT1[0] + V[6] * dT1[1] + V[10] * dT1[2];
+        const float dtx = x_grad_mul * -focal_x * itz2 * dJ02;
+        const float dty = y_grad_mul * -focal_y * itz2 * dJ12;
+        const float dtz = -focal_x * itz2 * dJ00 - focal_y * itz2 * dJ11 + (2.f * focal_x * tx) * itz3 * dJ02 +
+                          (2.f * focal_y * ty) * itz3 * dJ12;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dmean[i] = V[4 * i] * dtx + V[4 * i + 1] * dty + V[4 * i + 2] * dtz;
+
+        // ---- mean2D (NDC) -> mean ------------------------------------------------------------------------
+        const float hx = M[0] * x + M[4] * y + M[8] * z + M[12];
+        const float hy = M[1] * x + M[5] * y + M[9] * z + M[13];
+        const float hw = M[3] * x + M[7] * y + M[11] * z + M[15];
+        const float m_w = 1.0f / (hw + 0.0000001f);
+        const float mul1 = hx * m_w * m_w, mul2 = hy * m_w * m_w;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            dmean[i] += (M[4 * i] * m_w - M[4 * i + 3] * mul1) * dm2x + (M[4 * i + 1] * m_w - M[4 * i + 3] * mul2) * dm2y;
+        // ---- depth -> mean (ashawkey addition) ------------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dmean[i] += V[4 * i + 2] * d_depth;
+
+        // ---- colour -> SH, view direction -> mean ---------------------------------------------------------
+        if (shs != nullptr && dL_dsh != nullptr) {
+            if constexpr (C == 3) {
+                const uint32_t cl = clamped_in[idx];
+                const float dRGB[3] = {(cl & 1u) ? 0.f : gr[0], (cl & 2u) ? 0.f : gr[1], (cl & 4u) ? 0.f : gr[2]};
+                const float* sh = shs + (size_t)idx * sh_coeffs * 3;
+                float* dsh = dL_dsh + (size_t)idx * sh_coeffs * 3;
+                const float ox = x - campos[0], oy = y - campos[1], oz = z - campos[2];
+                const float il = rsqrtf(ox * ox + oy * oy + oz * oz);
+                const float dxn = ox * il, dyn = oy * il, dzn = oz * il;
+                float ddir[3] = {0.f, 0.f, 0.f};   // dL/d(normalised dir)
+                auto emit = [&](int k, float basis, float bx, float by, float bz) {
+                    // basis value -> dL/dsh[k]; basis gradient (bx,by,bz) * sh[k] -> dL/ddir
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        dsh[3 * k + ch] = basis * dRGB[ch];
+                        const float s = sh[3 * k + ch] * dRGB[ch];
+                        ddir[0] += bx * s; ddir[1] += by * s; ddir[2] += bz * s;
+                    }
+                };
+                emit(0, kC0, 0.f, 0.f, 0.f);
+                if (sh_degree > 0) {
+                    emit(1, -kC1 * dyn, 0.f, -kC1, 0.f);
+                    emit(2, kC1 * dzn, 0.f, 0.f, kC1);
+                    emit(3, -kC1 * dxn, -kC1, 0.f, 0.f);
+                    if (sh_degree > 1) {
+                        const float xx = dxn * dxn, yy = dyn * dyn, zz = dzn * dzn;
+                        const float xy = dxn * dyn, yz = dyn * dzn, xz = dxn * dzn;
+                        emit(4, kC2[0] * xy, kC2[0] * dyn, kC2[0] * dxn, 0.f);
+                        emit(5, kC2[1] * yz, 0.f, kC2[1] * dzn, kC2[1] * dyn);
+                        emit(6, kC2[2] * (2.f * zz - xx - yy), kC2[2] * -2.f * dxn, kC2[2] * -2.f * dyn, kC2[2] * 4.f * dzn);
+                        emit(7, kC2[3] * xz, kC2[3] * dzn, 0.f, kC2[3] * dxn);
+                        emit(8, kC2[4] * (xx - yy), kC2[4] * 2.f * dxn, kC2[4] * -2.f * dyn, 0.f);
+                        if (sh_degree > 2) {
+                            emit(9, kC3[0] * dyn * (3.f * xx - yy), kC3[0] * 6.f * xy, kC3[0] * (3.f * xx - 3.f * yy), 0.f);
+                            emit(10, kC3[1] * xy * dzn, kC3[1] * yz, kC3[1] * xz, kC3[1] * xy);
+                            emit(11, kC3[2] * dyn * (4.f * zz - xx - yy), kC3[2] * -2.f * xy,
+                                 kC3[2] * (4.f * zz - xx - 3.f * yy), kC3[2] * 8.f * yz);
+                            emit(12, kC3[3] * dzn * (2.f * zz - 3.f * xx - 3.f * yy), kC3[3] * -6.f * xz, kC3[3] * -6.f * yz,
+                                 kC3[3] * (6.f * zz - 3.f * xx - 3.f * yy));
+                            emit(13, kC3[4] * dxn * (4.f * zz - xx - yy), kC3[4] * (4.f * zz - 3.f * xx - yy),
+                                 kC3[4] * -2.f * xy, kC3[4] * 8.f * xz);
+                            emit(14, kC3[5] * dzn * (xx - yy), kC3[5] * 2.f * xz, kC3[5] * -2.f * yz, kC3[5] * (xx - yy));
+                            emit(15, kC3[6] * dxn * (xx - 3.f * yy), kC3[6] * (3.f * xx - 3.f * yy), kC3[6] * -6.f * xy, 0.f);
+                        }
+                    }
+                }
+                const int used = (sh_degree + 1) * (sh_degree + 1);
+                for (int k = used; k < sh_coeffs; ++k) { dsh[3 * k] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f; }
+                // d(dir/|dir|)/d(dir) = (I - n n^T) / |dir|
+                const float nd = dxn * ddir[0] + dyn * ddir[1] + dzn * ddir[2];
+                dmean[0] += (ddir[0] - dxn * nd) * il;
+                dmean[1] += (ddir[1] - dyn * nd) * il;
+                dmean[2] += (ddir[2] - dzn * nd) * il;
+            }
+        }
+
+        // ---- cov3D -> scale, rotation ------------------------------------------------------------------------
+        if (cov3D_precomp == nullptr && (dL_dscales || dL_drotations)) {
+            // G = dL/dSigma as a full symmetric matrix (off-diagonals halved), dL/dM = 2 G M, M_ik = R_ik s_k
+            const float G[9] = {dcov[0], 0.5f * dcov[1], 0.5f * dcov[2], 0.5f * dcov[1], dcov[3], 0.5f * dcov[4],
+                                0.5f * dcov[2], 0.5f * dcov[4], dcov[5]};
+            const float s[3] = {sx, sy, sz};
+            float dM[9];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    dM[3 * i + k] = 2.f * (G[3 * i] * Rm[k] * s[k] + G[3 * i + 1] * Rm[3 + k] * s[k] + G[3 * i + 2] * Rm[6 + k] * s[k]);
+            float dR[9];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                // NOTE: the reference omits the scale_modifier factor here (exact for modifier 1.0, A.5(v))
+                dscale[k] = Rm[k] * dM[k] + Rm[3 + k] * dM[3 + k] + Rm[6 + k] * dM[6 + k];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) dR[3 * i + k] = dM[3 * i + k] * s[k];
+            }
+            drot[0] = 2.f * (-qz * dR[1] + qy * dR[2] + qz * dR[3] - qx * dR[5] - qy * dR[6] + qx * dR[7]);
+            drot[1] = 2.f * (qy * dR[1] + qz * dR[2] + qy * dR[3] - 2.f * qx * dR[4] - qr * dR[5] + qz * dR[6] + qr * dR[7] -
+                             2.f * qx * dR[8]);
+            drot[2] = 2.f * (-2.f * qy * dR[0] + qx * dR[1] + qr * dR[2] + qx * dR[3] + qz * dR[5] - qr * dR[6] + qz * dR[7] -
+                             2.f * qy * dR[8]);
+            drot[3] = 2.f * (-2.f * qz * dR[0] - qr * dR[1] + qx * dR[2] + qr * dR[3] - 2.f * qz * dR[4] + qy * dR[5] +
+                             qx * dR[6] + qy * dR[7]);
+        }
+    } else if (dL_dsh != nullptr && shs != nullptr) {
+        float* dsh = dL_dsh + (size_t)idx * sh_coeffs * 3;
+        for (int k = 0; k < sh_coeffs * 3; ++k) dsh[k] = 0.f;
+    }
+
+    if (dL_dmeans3D) {
+        dL_dmeans3D[3 * idx] = dmean[0]; dL_dmeans3D[3 * idx + 1] = dmean[1]; dL_dmeans3D[3 * idx + 2] = dmean[2];
+    }
+    if (dL_dcov3D) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) dL_dcov3D[6 * idx + i] = dcov[i];
+    }
+    if (dL_dscales) {
+        dL_dscales[3 * idx] = dscale[0]; dL_dscales[3 * idx + 1] = dscale[1]; dL_dscales[3 * idx + 2] = dscale[2];
+    }
+    if (dL_drotations) {
+        reinterpret_cast<float4*>(dL_drotations)[idx] = make_float4(drot[0], drot[1], drot[2], drot[3]);
+    }
+}
+
+template <int C>
+int launch_c(const OgsRasterBwdArgs& a, const GeomState& gs, const float* grad_rec, hipStream_t s) {
+    const float focal_x = (float)a.W / (2.0f * a.tanfovx);
+    const float focal_y = (float)a.H / (2.0f * a.tanfovy);
+    const int grid = (a.P + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(preprocess_backward_kernel<C>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, a.sh_degree,
+                       a.sh_coeffs, a.tanfovx, a.tanfovy, focal_x, focal_y, a.scale_modifier, a.means3D, a.shs, a.scales,
+                       a.rotations, a.cov3D_precomp, a.viewmatrix, a.projmatrix, a.campos, a.radii,
+                       (const uint32_t*)gs.clamped, grad_rec, a.dL_dmeans2D, a.dL_dcolors, a.dL_dopacity, a.dL_dmeans3D,
+                       a.dL_dcov3D, a.dL_dsh, a.dL_dscales, a.dL_drotations);
+    OGS_LAUNCH_CHECK(a.debug, s);
+    return OGS_OK;
+}
+
+}  // namespace
+
+int launch_preprocess_backward(const OgsRasterBwdArgs& a, const GeomState& gs, const float* grad_rec, hipStream_t s) {
+    if (a.P <= 0) return OGS_OK;
+    switch (a.C) {
+        case 3: return launch_c<3>(a, gs, grad_rec, s);
+        case 6: return launch_c<6>(a, gs, grad_rec, s);
+        case 9: return launch_c<9>(a, gs, grad_rec, s);
+        default: set_error("backward: unsupported channel count C=%d", a.C); return OGS_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace ogs

@@ -1,0 +1,329 @@
+// Forward per-Gaussian preprocess for gfx950.
+//
+// COMPILED WITH -ffp-contract=off.  Every expression below is evaluated left-to-right in fp32 with
+// IEEE-rounded +,-,*,/ and sqrt, in exactly the order of oracle/raster_oracle.py::preprocess, so that
+// radii, tile rects and the depth bits (hence the (tile<<32 | depth) sort keys) are BIT-EXACT against
+// the oracle.  Do not "optimise" the arithmetic here without changing the oracle in lock-step.
+//
+// Memory behaviour: one thread per Gaussian, wave64-coalesced SoA reads of xyz/scale/rot/opacity, SH
+// coefficients read as 12 x float4 per Gaussian; one 16-byte-aligned record per Gaussian written
+// with float4 stores.  The kernel is HBM-bound (236 B in / ~70 B out per Gaussian with SH).
+#include "ogs_common.h"
+
+namespace ogs {
+
+namespace {
+
+__constant__ const float kC0 = 0.28209479177387814f;
+__constant__ const float kC1 = 0.4886025119029199f;
+__constant__ const float kC2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                   -1.0925484305920792f, 0.5462742152960396f};
+__constant__ const float kC3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                   0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                   -0.5900435899266435f};
+
+struct Cam {
+    float V[16];
+    float M[16];
+    float campos[3];
+};
+
+__device__ __forceinline__ void cov3d_from_scale_rot(const float* __restrict__ scales,
+                                                     const float* __restrict__ rots, int idx, float mod,
+                                                     float cov[6]) {
+    const float sx = mod * scales[3 * idx + 0], sy = mod * scales[3 * idx + 1], sz = mod * scales[3 * idx + 2];
+    const float4 q = reinterpret_cast<const float4*>(rots)[idx];
+    const float r = q.x, x = q.y, y = q.z, z = q.w;
+    const float R00 = 1.f - 2.f * (y * y + z * z), R01 = 2.f * (x * y - r * z), R02 = 2.f * (x * z + r * y);
+    const float R10 = 2.f * (x * y + r * z), R11 = 1.f - 2.f * (x * x + z * z), R12 = 2.f * (y * z - r * x);
+    const float R20 = 2.f * (x * z - r * y), R21 = 2.f * (y * z + r * x), R22 = 1.f - 2.f * (x * x + y * y);
+    const float M00 = R00 * sx, M01 = R01 * sy, M02 = R02 * sz;
+    const float M10 = R10 * sx, M11 = R11 * sy, M12 = R12 * sz;
+    const float M20 = R20 * sx, M21 = R21 * sy, M22 = R22 * sz;
+    cov[0] = M00 * M00 + M01 * M01 + M02 * M02;
+    cov[1] = M00 * M10 + M01 * M11 + M02 * M12;
+    cov[2] = M00 * M20 + M01 * M21 + M02 * M22;
+    cov[3] = M10 * M10 + M11 * M11 + M12 * M12;
+    cov[4] = M10 * M20 + M11 * M21 + M12 * M22;
+    cov[5] = M20 * M20 + M21 * M21 + M22 * M22;
+}
+
+// SH -> RGB (+0.5, clamp at 0).  shs: [P, M, 3] coefficient-major, channel-minor.
+__device__ __forceinline__ void sh_to_rgb(int idx, int deg, int M, const float* __restrict__ shs, float px,
+                                          float py, float pz, const float* campos, float rgb[3],
+                                          uint32_t& clamped) {
+    const float* sh = shs + (size_t)idx * M * 3;
+    float dx = px - campos[0], dy = py - campos[1], dz = pz - campos[2];
+    const float ln = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float x = dx / ln, y = dy / ln, z = dz / ln;
+    float res[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) res[c] = kC0 * sh[c];
+    if (deg > 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            res[c] = res[c] - kC1 * y * sh[3 + c] + kC1 * z * sh[6 + c] - kC1 * x * sh[9 + c];
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                res[c] = res[c] + kC2[0] * xy * sh[12 + c] + kC2[1] * yz * sh[15 + c] +
+                         kC2[2] * (2.f * zz - xx - yy) * sh[18 + c] + kC2[3] * xz * sh[21 + c] +
+                         kC2[4] * (xx - yy) * sh[24 + c];
+            if (deg > 2) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    res[c] = res[c] + kC3[0] * y * (3.f * xx - yy) * sh[27 + c] + kC3[1] * xy * z * sh[30 + c] +
+                             kC3[2] * y * (4.f * zz - xx - yy) * sh[33 + c] +
+                             kC3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * sh[36 + c] +
+                             kC3[4] * x * (4.f * zz - xx - yy) * sh[39 + c] + kC3[5] * z * (xx - yy) * sh[42 + c] +
+                             kC3[6] * x * (xx - 3.f * yy) * sh[45 + c];
+            }
+        }
+    }
+    clamped = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        res[c] = res[c] + 0.5f;
+        if (res[c] < 0.f) clamped |= 1u << c;
+        rgb[c] = fmaxf(res[c], 0.f);
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(kBlock) void preprocess_kernel(
+    int P, int W, int H, int sh_degree, int sh_coeffs, float tanfovx, float tanfovy, float focal_x, float focal_y,
+    float scale_modifier, const float* __restrict__ means3D, const float* __restrict__ colors_precomp,
+    const float* __restrict__ shs, const float* __restrict__ opacities, const float* __restrict__ scales,
+    const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix,
+    const float* __restrict__ projmatrix, const float* __restrict__ campos, float4* __restrict__ rec,
+    uint32_t* __restrict__ clamped_out, int32_t* __restrict__ radii, uint32_t* __restrict__ tiles_touched,
+    uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ order) {
+    constexpr int NV = rec_vec4(C);
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= P) return;
+
+    // camera matrices: wave-uniform addresses -> scalar loads
+    float V[16], M[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { V[i] = viewmatrix[i]; M[i] = projmatrix[i]; }
+
+    const float x = means3D[3 * idx + 0], y = means3D[3 * idx + 1], z = means3D[3 * idx + 2];
+    const float opacity = opacities[idx];
+
+    // blended features travel in the record even for culled Gaussians (kept simple: one writer)
+    float feat[(C + 3) / 4 * 4];
+#pragma unroll
+    for (int c = 0; c < (C + 3) / 4 * 4; ++c) feat[c] = 0.f;
+    uint32_t clamped = 0;
+
+    int radius = 0;
+    uint32_t touched = 0;
+    float pxl = 0.f, pyl = 0.f, depth = 0.f, cA = 0.f, cB = 0.f, cC = 0.f;
+
+    // 1. view space + near cull
+    const float pvx = V[0] * x + V[4] * y + V[8] * z + V[12];
+    const float pvy = V[1] * x + V[5] * y + V[9] * z + V[13];
+    const float pvz = V[2] * x + V[6] * y + V[10] * z + V[14];
+    bool ok = pvz > 0.2f;
+    if (ok) {
+        // 2. clip space
+        const float hx = M[0] * x + M[4] * y + M[8] * z + M[12];
+        const float hy = M[1] * x + M[5] * y + M[9] * z + M[13];
+        const float hw = M[3] * x + M[7] * y + M[11] * z + M[15];
+        const float p_w = 1.0f / (hw + 0.0000001f);
+        const float projx = hx * p_w, projy = hy * p_w;
+        // 3. 3D covariance
+        float cov[6];
+        if (cov3D_precomp != nullptr) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) cov[i] = cov3D_precomp[6 * idx + i];
+        } else {
+            cov3d_from_scale_rot(scales, rotations, idx, scale_modifier, cov);
+        }
+        // 4. EWA splat
+        const float limx = 1.3f * tanfovx, limy = 1.3f * tanfovy;
+        const float txtz = pvx / pvz, tytz = pvy / pvz;
+        const float tx = fminf(limx, fmaxf(-limx, txtz)) * pvz;
+        const float ty = fminf(limy, fmaxf(-limy, tytz)) * pvz;
+        const float tz = pvz;
+        const float J00 = focal_x / tz;
+        const float J02 = -(focal_x * tx) / (tz * tz);
+        const float J11 = focal_y / tz;
+        const float J12 = -(focal_y * ty) / (tz * tz);
+        const float T00 = J00 * V[0] + J02 * V[2];
+        const float T01 = J00 * V[4] + J02 * V[6];
+        const float T02 = J00 * V[8] + J02 * V[10];
+        const float T10 = J11 * V[1] + J12 * V[2];
+        const float T11 = J11 * V[5] + J12 * V[6];
+        const float T12 = J11 * V[9] + J12 * V[10];
+        const float a0 = T00 * cov[0] + T01 * cov[1] + T02 * cov[2];
+        const float a1 = T00 * cov[1] + T01 * cov[3] + T02 * cov[4];
+        const float a2 = T00 * cov[2] + T01 * cov[4] + T02 * cov[5];
+        const float b0 = T10 * cov[0] + T11 * cov[1] + T12 * cov[2];
+        const float b1 = T10 * cov[1] + T11 * cov[3] + T12 * cov[4];
+        const float b2 = T10 * cov[2] + T11 * cov[4] + T12 * cov[5];
+        const float ca = a0 * T00 + a1 * T01 + a2 * T02 + 0.3f;
+        const float cb = a0 * T10 + a1 * T11 + a2 * T12;
+        const float cc = b0 * T10 + b1 * T11 + b2 * T12 + 0.3f;
+        // 5. conic
+        const float det = ca * cc - cb * cb;
+        ok = det != 0.f;
+        if (ok) {
+            const float det_inv = 1.f / det;
+            cA = cc * det_inv;
+            cB = -cb * det_inv;
+            cC = ca * det_inv;
+            // 6. radius
+            const float mid = 0.5f * (ca + cc);
+            const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float lam = fmaxf(mid + sq, mid - sq);
+            float rad_f = ceilf(3.f * sqrtf(lam));
+            if (!(fabsf(rad_f) < 3.0e38f)) rad_f = 0.f;     // NaN / inf guard (matches the oracle)
+            const int my_radius = (int)rad_f;
+            // 7. pixel centre
+            pxl = ((projx + 1.0f) * (float)W - 1.0f) * 0.5f;
+            pyl = ((projy + 1.0f) * (float)H - 1.0f) * 0.5f;
+            // 8. tile rect
+            const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
+            const float rf = (float)my_radius;
+            auto tr = [](float v) -> int {
+                if (!(fabsf(v) < 3.0e38f)) v = 0.f;
+                v = fminf(fmaxf(v, -2.0e9f), 2.0e9f);
+                return (int)v;
+            };
+            const int rminx = min(gx, max(0, tr((pxl - rf) / (float)kTile)));
+            const int rminy = min(gy, max(0, tr((pyl - rf) / (float)kTile)));
+            const int rmaxx = min(gx, max(0, tr((pxl + rf + (float)kTile - 1.0f) / (float)kTile)));
+            const int rmaxy = min(gy, max(0, tr((pyl + rf + (float)kTile - 1.0f) / (float)kTile)));
+            const int area = (rmaxx - rminx) * (rmaxy - rminy);
+            ok = area != 0 && my_radius > 0;
+            if (ok) {
+                radius = my_radius;
+                touched = (uint32_t)area;
+                depth = pvz;
+            }
+        }
+    }
+
+    // 9. colour (the reference computes it only for surviving Gaussians; values of culled ones are
+    //    never read, so skipping the SH read for them saves bandwidth)
+    if (colors_precomp != nullptr) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) feat[c] = colors_precomp[(size_t)idx * C + c];
+    } else if (ok) {
+        if constexpr (C == 3) {
+            float rgb[3];
+            float cp[3] = {campos[0], campos[1], campos[2]};
+            sh_to_rgb(idx, sh_degree, sh_coeffs, shs, x, y, z, cp, rgb, clamped);
+            feat[0] = rgb[0]; feat[1] = rgb[1]; feat[2] = rgb[2];
+        }
+    }
+
+    if (!ok) { pxl = 0.f; pyl = 0.f; cA = cB = cC = 0.f; depth = 0.f; }
+
+    // 10. store
+    float4* r = rec + (size_t)idx * NV;
+    r[0] = make_float4(pxl, pyl, depth, __int_as_float(radius));
+    r[1] = make_float4(cA, cB, cC, opacity);
+#pragma unroll
+    for (int v = 0; v < NV - 2; ++v) r[2 + v] = make_float4(feat[4 * v], feat[4 * v + 1], feat[4 * v + 2], feat[4 * v + 3]);
+    clamped_out[idx] = clamped;
+    radii[idx] = radius;
+    tiles_touched[idx] = touched;
+    // depth-sort key: positive float bits are order preserving; culled Gaussians sort last
+    depth_keys[idx] = ok ? __float_as_uint(depth) : 0xFFFFFFFFu;
+    order[idx] = (uint32_t)idx;
+}
+
+// Emit one (tile id, Gaussian id) pair per touched tile, Gaussians visited in DEPTH order so that a
+// stable sort by tile id alone reproduces the reference's (tile<<32 | depth_bits) order with ties
+// broken by Gaussian index (DESIGN.md "binning").
+template <int NV>
+__global__ __launch_bounds__(kBlock) void duplicate_kernel(int P, int W, int H, const float4* __restrict__ rec,
+                                                           const uint32_t* __restrict__ order,
+                                                           const uint32_t* __restrict__ offsets,
+                                                           uint32_t* __restrict__ tile_keys,
+                                                           uint32_t* __restrict__ vals) {
+    const int r = blockIdx.x * kBlock + threadIdx.x;
+    if (r >= P) return;
+    const uint32_t gid = order[r];
+    const float4 a = rec[(size_t)gid * NV];
+    const int radius = __float_as_int(a.w);
+    if (radius <= 0) return;
+    const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
+    const float rf = (float)radius;
+    auto tr = [](float v) -> int {
+        if (!(fabsf(v) < 3.0e38f)) v = 0.f;
+        v = fminf(fmaxf(v, -2.0e9f), 2.0e9f);
+        return (int)v;
+    };
+    const int rminx = min(gx, max(0, tr((a.x - rf) / (float)kTile)));
+    const int rminy = min(gy, max(0, tr((a.y - rf) / (float)kTile)));
+    const int rmaxx = min(gx, max(0, tr((a.x + rf + (float)kTile - 1.0f) / (float)kTile)));
+    const int rmaxy = min(gy, max(0, tr((a.y + rf + (float)kTile - 1.0f) / (float)kTile)));
+    uint32_t off = offsets[r];
+    for (int ty = rminy; ty < rmaxy; ++ty)
+        for (int tx = rminx; tx < rmaxx; ++tx) {
+            tile_keys[off] = (uint32_t)(ty * gx + tx);
+            vals[off] = gid;
+            ++off;
+        }
+}
+
+__global__ __launch_bounds__(kBlock) void mark_visible_kernel(int P, const float* __restrict__ means3D,
+                                                              const float* __restrict__ V,
+                                                              uint8_t* __restrict__ present) {
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= P) return;
+    const float x = means3D[3 * idx], y = means3D[3 * idx + 1], z = means3D[3 * idx + 2];
+    const float pvz = V[2] * x + V[6] * y + V[10] * z + V[14];
+    present[idx] = pvz > 0.2f ? 1 : 0;
+}
+
+template <int C>
+int launch_preprocess_c(const OgsRasterFwdArgs& a, const GeomState& gs, const GeomTmp& gt, hipStream_t s) {
+    const float focal_x = (float)a.W / (2.0f * a.tanfovx);
+    const float focal_y = (float)a.H / (2.0f * a.tanfovy);
+    const int grid = (a.P + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(preprocess_kernel<C>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, a.sh_degree, a.sh_coeffs,
+                       a.tanfovx, a.tanfovy, focal_x, focal_y, a.scale_modifier, a.means3D, a.colors_precomp, a.shs,
+                       a.opacities, a.scales, a.rotations, a.cov3D_precomp, a.viewmatrix, a.projmatrix, a.campos,
+                       gs.rec, gs.clamped, a.radii, gt.tiles_touched, gt.keys[0], gt.order[0]);
+    OGS_LAUNCH_CHECK(a.debug, s);
+    return OGS_OK;
+}
+
+}  // namespace
+
+int launch_preprocess(const OgsRasterFwdArgs& a, const GeomState& gs, const GeomTmp& gt, hipStream_t s) {
+    switch (a.C) {
+        case 3: return launch_preprocess_c<3>(a, gs, gt, s);
+        case 6: return launch_preprocess_c<6>(a, gs, gt, s);
+        case 9: return launch_preprocess_c<9>(a, gs, gt, s);
+        case 12: return launch_preprocess_c<12>(a, gs, gt, s);
+        default: set_error("unsupported channel count C=%d (3, 6, 9 or 12)", a.C); return OGS_ERR_UNSUPPORTED;
+    }
+}
+
+int launch_duplicate(const OgsRasterFwdArgs& a, const GeomState& gs, const GeomTmp& gt, uint32_t* tile_keys,
+                     uint32_t* vals, hipStream_t s) {
+    const int grid = (a.P + kBlock - 1) / kBlock;
+    switch (rec_vec4(a.C)) {
+        case 3: hipLaunchKernelGGL(duplicate_kernel<3>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals); break;
+        case 4: hipLaunchKernelGGL(duplicate_kernel<4>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals); break;
+        case 5: hipLaunchKernelGGL(duplicate_kernel<5>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals); break;
+        default: set_error("unsupported record size"); return OGS_ERR_UNSUPPORTED;
+    }
+    OGS_LAUNCH_CHECK(a.debug, s);
+    return OGS_OK;
+}
+
+int launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s) {
+    const int grid = (P + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(mark_visible_kernel, dim3(grid), dim3(kBlock), 0, s, P, means3D, viewmatrix, present);
+    OGS_LAUNCH_CHECK(0, s);
+    return OGS_OK;
+}
+
+}  // namespace ogs

@@ -1,0 +1,227 @@
+"""Drop-in Python surface of the reference's rasterizer package.
+
+Mirrors ``ashawkey_diff_gaussian_rasterization`` as the reference uses it
+(/root/reference/gaussian_renderer/__init__.py:15,55-70,104-112; utils/sam_refinement_utils.py:21,347-402):
+``GaussianRasterizationSettings`` (12-field NamedTuple), ``GaussianRasterizer(raster_settings=...)`` called with
+keyword args ``means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp`` and
+returning ``(color[3,H,W], radii[P] int32, depth[1,H,W], alpha[1,H,W])``; ``markVisible(positions)``.
+
+Underneath is the C ABI of include/ogs_raster.h (HIP kernels for gfx950) bound with ctypes; torch only
+provides device memory, the current stream and autograd.  There is no CPU path: non-GPU tensors raise.
+
+Extension beyond the reference API: ``colors_precomp`` may carry 3, 6, 9 or 12
+channels; one pass then bins/sorts once and blends all channels (``color`` is [C,H,W]).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import NamedTuple, Optional
+
+import torch
+from torch import nn
+
+from . import _lib
+from ._lib import OgsRasterBwdArgs, OgsRasterFwdArgs, check, ptr
+
+SUPPORTED_CHANNELS = (3, 6, 9, 12)
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """contiguous fp32 view/copy (inputs may be sliced / boolean-indexed views, :133,204-212)."""
+    if t is None or t.numel() == 0:
+        return None
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _require_gpu(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (got {t.device}); the MI355X rasterizer has no CPU path")
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings: GaussianRasterizationSettings):
+        rs = raster_settings
+        _require_gpu(means3D, "means3D")
+        dev = means3D.device
+        lib = _lib.lib()
+        P = int(means3D.shape[0])
+        H, W = int(rs.image_height), int(rs.image_width)
+        if means3D.dim() != 2 or means3D.shape[1] != 3:
+            raise RuntimeError("means3D must have dimensions (num_points, 3)")
+
+        m3 = _f32c(means3D)
+        shs = _f32c(sh)
+        cols = _f32c(colors_precomp)
+        opac = _f32c(opacities)
+        scl = _f32c(scales)
+        rot = _f32c(rotations)
+        cov = _f32c(cov3Ds_precomp)
+        Cn = 3 if cols is None else int(cols.shape[1])
+        if Cn not in SUPPORTED_CHANNELS:
+            raise RuntimeError(f"colors_precomp must have 3, 6, 9 or 12 channels, got {Cn}")
+        bg = _f32c(rs.bg.to(dev))
+        if bg is None or bg.numel() != Cn:
+            if bg is not None and bg.numel() == 3 and Cn > 3:      # facade bg is 3-wide: pad with zeros
+                bg = torch.cat([bg, torch.zeros(Cn - 3, device=dev)])
+            else:
+                raise RuntimeError(f"bg must have {Cn} entries")
+        view = _f32c(rs.viewmatrix.to(dev))
+        proj = _f32c(rs.projmatrix.to(dev))
+        campos = _f32c(rs.campos.to(dev))
+
+        color = torch.zeros(Cn, H, W, dtype=torch.float32, device=dev)
+        depth = torch.zeros(1, H, W, dtype=torch.float32, device=dev)
+        alpha = torch.zeros(1, H, W, dtype=torch.float32, device=dev)
+        radii = torch.zeros(P, dtype=torch.int32, device=dev)
+        ctx.raster_settings = rs
+        ctx.P, ctx.Cn, ctx.num_rendered = P, Cn, 0
+        if P == 0:
+            # reference behaviour: zero images, nothing launched (SURVEY.md section 8(b) "Errors")
+            ctx.save_for_backward()
+            ctx.mark_non_differentiable(radii)
+            return color, radii, depth, alpha
+
+        u8 = lambda n: torch.empty(int(n), dtype=torch.uint8, device=dev)
+        geom = u8(lib.ogs_raster_geom_bytes(P, Cn))
+        geom_tmp = u8(lib.ogs_raster_geom_tmp_bytes(P))
+        image = u8(lib.ogs_raster_image_bytes(W, H))
+
+        a = OgsRasterFwdArgs()
+        a.P, a.W, a.H, a.C = P, W, H, Cn
+        a.sh_degree = int(rs.sh_degree)
+        a.sh_coeffs = 0 if shs is None else int(shs.shape[1])
+        a.tanfovx, a.tanfovy, a.scale_modifier = float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier)
+        a.prefiltered, a.debug = int(bool(rs.prefiltered)), int(bool(rs.debug))
+        a.bg, a.means3D, a.colors_precomp, a.shs, a.opacities = ptr(bg), ptr(m3), ptr(cols), ptr(shs), ptr(opac)
+        a.scales, a.rotations, a.cov3D_precomp = ptr(scl), ptr(rot), ptr(cov)
+        a.viewmatrix, a.projmatrix, a.campos = ptr(view), ptr(proj), ptr(campos)
+        a.out_color, a.out_depth, a.out_alpha, a.radii = ptr(color), ptr(depth), ptr(alpha), ptr(radii)
+        a.geom_buffer, a.geom_tmp, a.image_buffer = ptr(geom), ptr(geom_tmp), ptr(image)
+
+        stream = _stream()
+        n = C.c_int64(0)
+        check(lib.ogs_raster_forward_geometry(C.byref(a), stream, C.byref(n)), "ogs_raster_forward_geometry")
+        D = int(n.value)
+        point_list = torch.empty(max(D, 1), dtype=torch.int32, device=dev)
+        bin_tmp = u8(lib.ogs_raster_binning_tmp_bytes(D, W, H))
+        a.point_list, a.binning_tmp = ptr(point_list), ptr(bin_tmp)
+        check(lib.ogs_raster_forward_render(C.byref(a), D, stream), "ogs_raster_forward_render")
+
+        ctx.num_rendered = D
+        ctx.save_for_backward(m3, shs, cols, opac, scl, rot, cov, bg, view, proj, campos, radii, alpha, geom, image,
+                              point_list)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth, alpha
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
+        rs = ctx.raster_settings
+        P, Cn = ctx.P, ctx.Cn
+        if P == 0:
+            return (None,) * 9
+        (m3, shs, cols, opac, scl, rot, cov, bg, view, proj, campos, radii, alpha, geom, image,
+         point_list) = ctx.saved_tensors
+        dev = m3.device
+        lib = _lib.lib()
+        H, W = int(rs.image_height), int(rs.image_width)
+        need = ctx.needs_input_grad   # means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D
+        z = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+
+        g_m3 = z(P, 3) if need[0] else None
+        g_m2 = z(P, 3) if need[1] else None
+        g_sh = z(*shs.shape) if (need[2] and shs is not None) else None
+        g_col = z(P, Cn) if (need[3] and cols is not None) else None
+        g_op = z(P, 1) if need[4] else None
+        g_scl = z(P, 3) if (need[5] and scl is not None) else None
+        g_rot = z(P, 4) if (need[6] and rot is not None) else None
+        g_cov = z(P, 6) if (need[7] and cov is not None) else None
+
+        gc = _f32c(grad_color)
+        if gc is None:
+            gc = torch.zeros(Cn, H, W, dtype=torch.float32, device=dev)
+        gd = _f32c(grad_depth)
+        ga = _f32c(grad_alpha)
+        bwd_tmp = torch.empty(int(lib.ogs_raster_backward_tmp_bytes(P)), dtype=torch.uint8, device=dev)
+
+        b = OgsRasterBwdArgs()
+        b.P, b.W, b.H, b.C = P, W, H, Cn
+        b.sh_degree = int(rs.sh_degree)
+        b.sh_coeffs = 0 if shs is None else int(shs.shape[1])
+        b.tanfovx, b.tanfovy, b.scale_modifier = float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier)
+        b.debug = int(bool(rs.debug))
+        b.num_rendered = int(ctx.num_rendered)
+        b.bg, b.means3D, b.colors_precomp, b.shs, b.opacities = ptr(bg), ptr(m3), ptr(cols), ptr(shs), ptr(opac)
+        b.scales, b.rotations, b.cov3D_precomp = ptr(scl), ptr(rot), ptr(cov)
+        b.viewmatrix, b.projmatrix, b.campos = ptr(view), ptr(proj), ptr(campos)
+        b.radii, b.out_alpha = ptr(radii), ptr(alpha)
+        b.dL_dcolor, b.dL_ddepth, b.dL_dalpha = ptr(gc), ptr(gd), ptr(ga)
+        b.geom_buffer, b.image_buffer, b.point_list, b.bwd_tmp = ptr(geom), ptr(image), ptr(point_list), ptr(bwd_tmp)
+        b.dL_dmeans2D, b.dL_dcolors, b.dL_dopacity, b.dL_dmeans3D = ptr(g_m2), ptr(g_col), ptr(g_op), ptr(g_m3)
+        b.dL_dcov3D, b.dL_dsh, b.dL_dscales, b.dL_drotations = ptr(g_cov), ptr(g_sh), ptr(g_scl), ptr(g_rot)
+        check(lib.ogs_raster_backward(C.byref(b), _stream()), "ogs_raster_backward")
+        return g_m3, g_m2, g_sh, g_col, g_op, g_scl, g_rot, g_cov, None
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
+        """bool[P]: near-plane test (upstream `mark_visible`; unused by the reference's own code)."""
+        _require_gpu(positions, "positions")
+        rs = self.raster_settings
+        with torch.no_grad():
+            pos = _f32c(positions)
+            P = 0 if pos is None else int(pos.shape[0])
+            out = torch.zeros(P, dtype=torch.uint8, device=positions.device)
+            if P:
+                view = _f32c(rs.viewmatrix.to(positions.device))
+                proj = _f32c(rs.projmatrix.to(positions.device))
+                check(_lib.lib().ogs_mark_visible(P, ptr(pos), ptr(view), ptr(proj), ptr(out), _stream()),
+                      "ogs_mark_visible")
+        return out.bool()
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        rs = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        empty = torch.Tensor([])
+        shs = empty if shs is None else shs
+        colors_precomp = empty if colors_precomp is None else colors_precomp
+        scales = empty if scales is None else scales
+        rotations = empty if rotations is None else rotations
+        cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                   cov3D_precomp, rs)

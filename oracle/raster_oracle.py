@@ -200,6 +200,7 @@ def preprocess(means3D, opacities, viewmatrix, projmatrix, campos, W, H, tanfovx
         rad_f = np.ceil(F(3.0) * np.sqrt(lam))
         rad_f = np.where(np.isfinite(rad_f), rad_f, F(0.0))
         radius = rad_f.astype(np.int32)
+        ok &= radius > 0
         # 7. pixel centre
         px = ((projx + F(1.0)) * F(W) - F(1.0)) * F(0.5)
         py = ((projy + F(1.0)) * F(H) - F(1.0)) * F(0.5)
@@ -424,8 +425,11 @@ def preprocess_t(means3D, means2D, opacities, viewmatrix, projmatrix, campos, W,
     Sxx, Sxy, Sxz, Syy, Syz, Szz = (cov[:, i] for i in range(6))
     fx = W / (2.0 * tanfovx); fy = H / (2.0 * tanfovy)
     limx, limy = 1.3 * tanfovx, 1.3 * tanfovy
-    tx = torch.clamp(pvx / pvz, -limx, limx) * pvz
-    ty = torch.clamp(pvy / pvz, -limy, limy) * pvz
+    # A.5: where the +-1.3*tanfov clamp is active the reference zeroes the x / y gradient path and does
+    # NOT propagate through the clamped value's dependence on z -> detach the clamped branch.
+    txtz, tytz = pvx / pvz, pvy / pvz
+    tx = torch.where(txtz.abs() <= limx, pvx, (torch.clamp(txtz, -limx, limx) * pvz).detach())
+    ty = torch.where(tytz.abs() <= limy, pvy, (torch.clamp(tytz, -limy, limy) * pvz).detach())
     tz = pvz
     J00 = fx / tz; J02 = -(fx * tx) / (tz * tz); J11 = fy / tz; J12 = -(fy * ty) / (tz * tz)
     T00 = J00 * V[0] + J02 * V[2]; T01 = J00 * V[4] + J02 * V[6]; T02 = J00 * V[8] + J02 * V[10]

@@ -1,0 +1,90 @@
+"""Shared helpers for the parity tests: build seeded scenes, run the HIP path through the drop-in API and
+the CPU oracle on identical inputs."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from opengaussian_amd.synthetic import make_camera, make_scene
+
+
+def tiny_scene(P, W, H, f, seed=0, log_scale_mean=-3.0, with_ties=False):
+    sc = make_scene(P, W, H, f, f, seed=seed, log_scale_mean=log_scale_mean)
+    cam = make_camera(W, H, f, f)
+    if with_ties and P >= 8:
+        # exact depth ties (same z) to exercise the stable tie-break by Gaussian index
+        sc.means3D[1::4, 2] = sc.means3D[0::4, 2][: sc.means3D[1::4].shape[0]]
+    return sc, cam
+
+
+def oracle_inputs(sc, cam, use_sh=True, use_cov=False, feat=None):
+    from oracle import raster_oracle as ro
+    inp = dict(means3D=sc.means3D.numpy(), opacities=sc.opacities.numpy(),
+               viewmatrix=cam.world_view_transform.numpy(), projmatrix=cam.full_proj_transform.numpy(),
+               campos=cam.camera_center.numpy())
+    if use_cov:
+        inp["cov3D_precomp"] = ro.cov3d_from_scale_rot(sc.scales.numpy(), sc.rotations.numpy(), 1.0)
+    else:
+        inp["scales"] = sc.scales.numpy()
+        inp["rotations"] = sc.rotations.numpy()
+    if feat is not None:
+        inp["colors_precomp"] = feat.numpy()
+    elif use_sh:
+        inp["shs"] = sc.shs.numpy()
+    else:
+        inp["colors_precomp"] = sc.ins_feat[:, :3].contiguous().numpy()
+    return inp
+
+
+def settings_for(cam, bg, sh_degree, device, debug=False):
+    from opengaussian_amd.rasterizer import GaussianRasterizationSettings
+    import math
+    return GaussianRasterizationSettings(
+        image_height=cam.image_height, image_width=cam.image_width,
+        tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
+        bg=torch.as_tensor(bg, dtype=torch.float32, device=device), scale_modifier=1.0,
+        viewmatrix=cam.world_view_transform.to(device), projmatrix=cam.full_proj_transform.to(device),
+        sh_degree=sh_degree, campos=cam.camera_center.to(device), prefiltered=False, debug=debug)
+
+
+def hip_forward(inp, cam, bg, sh_degree, device, requires_grad=False, debug=False):
+    """Run GaussianRasterizer on `device` with the same arrays as the oracle.  Returns (outputs, leaves)."""
+    from opengaussian_amd.rasterizer import GaussianRasterizer
+    t = lambda k: (None if inp.get(k) is None else
+                   torch.tensor(np.asarray(inp[k]), dtype=torch.float32, device=device, requires_grad=requires_grad))
+    leaves = {k: t(k) for k in ("means3D", "opacities", "scales", "rotations", "cov3D_precomp", "shs", "colors_precomp")}
+    P = leaves["means3D"].shape[0]
+    leaves["means2D"] = torch.zeros(P, 3, dtype=torch.float32, device=device, requires_grad=requires_grad)
+    rast = GaussianRasterizer(settings_for(cam, bg, sh_degree, device, debug))
+    out = rast(means3D=leaves["means3D"], means2D=leaves["means2D"], opacities=leaves["opacities"],
+               shs=leaves["shs"], colors_precomp=leaves["colors_precomp"], scales=leaves["scales"],
+               rotations=leaves["rotations"], cov3D_precomp=leaves["cov3D_precomp"])
+    return out, leaves
+
+
+def hip_export_binning(color_tensor):
+    """Fetch sorted keys / ranges / n_contrib of the forward pass that produced `color_tensor`."""
+    from opengaussian_amd import _lib
+    from opengaussian_amd._lib import OgsRasterFwdArgs, ptr
+    fn = color_tensor.grad_fn
+    ctx = fn
+    (m3, shs, cols, opac, scl, rot, cov, bg, view, proj, campos, radii, alpha, geom, image,
+     point_list) = ctx.saved_tensors
+    rs = ctx.raster_settings
+    D = ctx.num_rendered
+    W, H = int(rs.image_width), int(rs.image_height)
+    dev = m3.device
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    keys = torch.zeros(max(D, 1), dtype=torch.int64, device=dev)
+    ranges = torch.zeros(gx * gy, 2, dtype=torch.int32, device=dev)
+    ncontrib = torch.zeros(H, W, dtype=torch.int32, device=dev)
+    a = OgsRasterFwdArgs()
+    a.P, a.W, a.H, a.C = ctx.P, W, H, ctx.Cn
+    a.geom_buffer, a.image_buffer, a.point_list = ptr(geom), ptr(image), ptr(point_list)
+    _lib.check(_lib.lib().ogs_raster_export_binning(C.byref(a), D, ptr(keys), ptr(ranges), ptr(ncontrib),
+                                                    torch.cuda.current_stream().cuda_stream), "export_binning")
+    torch.cuda.synchronize()
+    return (keys[:D].cpu().numpy().view(np.uint64), ranges.cpu().numpy().view(np.uint32),
+            ncontrib.cpu().numpy().view(np.uint32), point_list[:D].cpu().numpy().view(np.uint32))

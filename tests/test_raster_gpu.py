@@ -1,0 +1,175 @@
+"""GPU parity tests: HIP rasterizer (through the drop-in GaussianRasterizer -> C ABI) vs the CPU oracle on
+identical seeded inputs.  Tolerances (BASELINE.json north_star): images / depth / alpha within 1e-4 fp32;
+radii, tile ranges, sorted (tile<<32 | depth_bits) keys and point lists BIT-EXACT; n_contrib exact except
+for pixels where the device exp and the host exp disagree on a threshold (bounded fraction, documented)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+IMG_TOL = 1e-4
+
+
+def _fwd_case(P, W, H, f, seed, use_sh, use_cov, device, lsm=-3.0, ties=False, bg=(0.1, 0.2, 0.3)):
+    from oracle import raster_oracle as ro
+    sc, cam = helpers.tiny_scene(P, W, H, f, seed=seed, log_scale_mean=lsm, with_ties=ties)
+    inp = helpers.oracle_inputs(sc, cam, use_sh=use_sh, use_cov=use_cov)
+    ref = ro.render_forward(W=W, H=H, tanfovx=W / (2 * f), tanfovy=H / (2 * f), bg=np.array(bg, np.float32),
+                            sh_degree=3, **inp)
+    (color, radii, depth, alpha), leaves = helpers.hip_forward(inp, cam, bg, 3, device, requires_grad=True)
+    keys, ranges, ncontrib, plist = helpers.hip_export_binning(color)
+    return ref, color, radii, depth, alpha, keys, ranges, ncontrib, plist
+
+
+CASES = [
+    # P, W, H, f, seed, use_sh, use_cov
+    (2000, 160, 96, 120.0, 0, True, False),
+    (1500, 100, 77, 90.0, 1, False, False),      # sizes not multiples of 16, colours precomputed
+    (1200, 64, 48, 60.0, 2, True, True),         # cov3D_precomp path
+    (5000, 320, 200, 250.0, 3, True, False),
+]
+
+
+@pytest.mark.parametrize("P,W,H,f,seed,use_sh,use_cov", CASES)
+def test_forward_parity(gpu_device, P, W, H, f, seed, use_sh, use_cov):
+    ref, color, radii, depth, alpha, keys, ranges, ncontrib, plist = _fwd_case(
+        P, W, H, f, seed, use_sh, use_cov, gpu_device, ties=(seed == 3))
+    g, b = ref["geom"], ref["binning"]
+    # integers: bit exact
+    np.testing.assert_array_equal(radii.cpu().numpy(), g.radii)
+    assert len(keys) == b.num_rendered
+    np.testing.assert_array_equal(keys, b.keys_sorted)
+    np.testing.assert_array_equal(plist, b.point_list)
+    np.testing.assert_array_equal(ranges, b.ranges)
+    # floats: 1e-4
+    np.testing.assert_allclose(color.detach().cpu().numpy(), ref["color"], atol=IMG_TOL, rtol=0)
+    np.testing.assert_allclose(alpha.detach().cpu().numpy(), ref["alpha"], atol=IMG_TOL, rtol=0)
+    # depth is an un-normalised sum of z*w with z up to 10: scale the absolute tolerance by max depth
+    np.testing.assert_allclose(depth.detach().cpu().numpy(), ref["depth"], atol=IMG_TOL * 10, rtol=0)
+    mism = (ncontrib != ref["n_contrib"].astype(np.uint32)).mean()
+    assert mism < 2e-3, f"n_contrib mismatch fraction {mism}"
+
+
+def test_wave_fold16(gpu_device):
+    from opengaussian_amd import _lib
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(64, 16, generator=g)
+    # asymmetric integer pattern as well, to catch permutation errors exactly
+    xi = (torch.arange(64)[:, None] * 17 + torch.arange(16)[None, :] * 3 + 1).float()
+    for inp in (x, xi):
+        d = inp.to(gpu_device).contiguous()
+        out = torch.zeros(64, device=gpu_device)
+        _lib.check(_lib.lib().ogs_selftest_wave_fold16(d.data_ptr(), out.data_ptr(), 0), "selftest")
+        torch.cuda.synchronize()
+        expect = inp.double().sum(0)[torch.arange(64) // 4].float()
+        torch.testing.assert_close(out.cpu(), expect, rtol=1e-5, atol=1e-4)
+
+
+def test_sh_path_equals_precomputed_colors(gpu_device):
+    """gaussian_renderer/__init__.py:92-97: rasterizer SH path == colors_precomp = clamp_min(eval_sh + 0.5, 0)."""
+    from oracle import raster_oracle as ro
+    sc, cam = helpers.tiny_scene(3000, 200, 120, 150.0, seed=5)
+    inp_sh = helpers.oracle_inputs(sc, cam, use_sh=True)
+    rgb, _ = ro.eval_sh_rgb(3, sc.shs.numpy(), sc.means3D.numpy(), cam.camera_center.numpy())
+    inp_pc = helpers.oracle_inputs(sc, cam, feat=torch.from_numpy(rgb))
+    (c1, r1, d1, a1), _ = helpers.hip_forward(inp_sh, cam, (0, 0, 0), 3, gpu_device)
+    (c2, r2, d2, a2), _ = helpers.hip_forward(inp_pc, cam, (0, 0, 0), 3, gpu_device)
+    assert torch.equal(r1, r2)
+    torch.testing.assert_close(c1, c2, atol=2e-6, rtol=0)
+    torch.testing.assert_close(a1, a2, atol=0, rtol=0)
+
+
+def test_scale_rot_path_equals_cov3d_precomp(gpu_device):
+    """gaussian_renderer/__init__.py:81-85 + scene/gaussian_model.py:41-45."""
+    sc, cam = helpers.tiny_scene(3000, 200, 120, 150.0, seed=6)
+    (c1, r1, d1, a1), _ = helpers.hip_forward(helpers.oracle_inputs(sc, cam, use_cov=False), cam, (0, 0, 0), 3, gpu_device)
+    (c2, r2, d2, a2), _ = helpers.hip_forward(helpers.oracle_inputs(sc, cam, use_cov=True), cam, (0, 0, 0), 3, gpu_device)
+    assert torch.equal(r1, r2)
+    torch.testing.assert_close(c1, c2, atol=0, rtol=0)
+
+
+def _grad_check(inp, cam, W, H, f, device, sh_degree=3, bg=(0.1, 0.2, 0.3), seed=0):
+    from oracle import raster_oracle as ro
+    ref = ro.render_forward(W=W, H=H, tanfovx=W / (2 * f), tanfovy=H / (2 * f), bg=np.array(bg, np.float32),
+                            sh_degree=sh_degree, **inp)
+    Cn = ref["color"].shape[0]
+    rng = np.random.default_rng(seed)
+    gC, gD, gA = rng.standard_normal((Cn, H, W)), rng.standard_normal((1, H, W)), rng.standard_normal((1, H, W))
+    gref = ro.render_backward_f64(inp, ref["binning"], W, H, W / (2 * f), H / (2 * f), np.array(bg, np.float64),
+                                  gC, gD, gA, sh_degree=sh_degree)
+    (color, radii, depth, alpha), leaves = helpers.hip_forward(inp, cam, bg, sh_degree, device, requires_grad=True)
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=device)
+    loss = (color * t(gC)).sum() + (depth * t(gD)).sum() + (alpha * t(gA)).sum()
+    loss.backward()
+    out = {}
+    for k, v in leaves.items():
+        if v is None or gref.get(k) is None:
+            continue
+        got = v.grad.detach().cpu().double().numpy()
+        want = gref[k].reshape(got.shape)
+        scale = np.abs(want).max() + 1e-12
+        out[k] = float(np.abs(got - want).max() / scale)
+    return out
+
+
+# max |hip - f64 autograd| / max |f64 autograd| per gradient family.  fp32 recomputation of T by division,
+# the 1/(det^2 + 1e-7) regulariser of A.5 and float atomics bound this at ~1e-4..1e-3, not 1e-7.
+GRAD_TOL = 2e-3
+
+
+@pytest.mark.parametrize("use_sh,use_cov,seed", [(True, False, 0), (False, False, 1), (True, True, 2)])
+def test_backward_parity(gpu_device, use_sh, use_cov, seed):
+    W, H, f = 128, 80, 100.0
+    sc, cam = helpers.tiny_scene(1500, W, H, f, seed=seed)
+    inp = helpers.oracle_inputs(sc, cam, use_sh=use_sh, use_cov=use_cov)
+    errs = _grad_check(inp, cam, W, H, f, gpu_device, seed=seed)
+    assert errs, "no gradients compared"
+    for k, e in errs.items():
+        assert e < GRAD_TOL, f"{k}: relative error {e} (all: {errs})"
+
+
+def test_backward_parity_6ch(gpu_device):
+    """fused 6-channel ins_feat pass (colors_precomp [P,6]) forward + backward."""
+    W, H, f = 96, 64, 80.0
+    sc, cam = helpers.tiny_scene(1000, W, H, f, seed=7)
+    inp = helpers.oracle_inputs(sc, cam, feat=sc.ins_feat)
+    errs = _grad_check(inp, cam, W, H, f, gpu_device, bg=(0,) * 6, seed=7)
+    for k, e in errs.items():
+        assert e < GRAD_TOL, f"{k}: relative error {e} (all: {errs})"
+
+
+def test_empty_and_degenerate(gpu_device):
+    from opengaussian_amd.rasterizer import GaussianRasterizer
+    sc, cam = helpers.tiny_scene(64, 64, 48, 60.0, seed=9)
+    dev = gpu_device
+    rs = helpers.settings_for(cam, (0.5, 0.25, 0.125), 3, dev)
+    rast = GaussianRasterizer(rs)
+    # P == 0: zero images, no bg (reference behaviour)
+    e = lambda *s: torch.zeros(*s, device=dev)
+    c, r, d, a = rast(means3D=e(0, 3), means2D=e(0, 3), opacities=e(0, 1), shs=e(0, 16, 3), scales=e(0, 3), rotations=e(0, 4))
+    assert c.shape == (3, 48, 64) and r.shape == (0,) and float(c.abs().max()) == 0.0
+    # everything behind the camera: bg only, radii all zero
+    m = sc.means3D.clone(); m[:, 2] = -1.0
+    c, r, d, a = rast(means3D=m.to(dev), means2D=e(64, 3), opacities=sc.opacities.to(dev), shs=sc.shs.to(dev),
+                      scales=sc.scales.to(dev), rotations=sc.rotations.to(dev))
+    assert int(r.abs().sum()) == 0
+    torch.testing.assert_close(c[:, 0, 0].cpu(), torch.tensor([0.5, 0.25, 0.125]))
+    assert float(a.abs().max()) == 0.0
+    # P == 1 (the SAM refiner's single-Gaussian footprint query, utils/sam_refinement_utils.py:330-403)
+    c, r, d, a = rast(means3D=torch.tensor([[0.0, 0.0, 3.0]], device=dev), means2D=e(1, 3),
+                      opacities=torch.tensor([[0.9]], device=dev), shs=sc.shs[:1].to(dev),
+                      scales=torch.tensor([[0.05, 0.05, 0.05]], device=dev),
+                      rotations=torch.tensor([[1.0, 0, 0, 0]], device=dev))
+    assert int(r[0]) > 0 and float(a.max()) > 0.5
+    # validation errors of the facade
+    with pytest.raises(Exception):
+        rast(means3D=m.to(dev), means2D=e(64, 3), opacities=sc.opacities.to(dev), scales=sc.scales.to(dev),
+             rotations=sc.rotations.to(dev))
+    with pytest.raises(Exception):
+        rast(means3D=m.to(dev), means2D=e(64, 3), opacities=sc.opacities.to(dev), shs=sc.shs.to(dev))
+    vis = rast.markVisible(sc.means3D.to(dev))
+    assert vis.dtype == torch.bool and vis.shape == (64,)
+    assert torch.equal(vis.cpu(), sc.means3D[:, 2] > 0.2)
