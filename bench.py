@@ -1,0 +1,296 @@
+#!/usr/bin/env python
+"""bench.py -- fwd+bwd Mpix/s of the MI355X rasterizer hot path on the BASELINE.json workload.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json `metric`): synthetic S1M-1080p scene -- 1,000,000 Gaussians,
+1920x1080, seed 0 -- one "step" = one VIEW rendered forward AND backward with everything the metric names:
+  pass A  RGB through SH degree 3 (+depth, alpha), backward to means3D / scales / rotations / opacity / SH /
+          means2D  (stage-0 style, all gradient families),
+  pass B  the 6-D ins_feat map as ONE fused 6-channel pass (the reference needs two 3-channel passes,
+          gaussian_renderer/__init__.py:129-151), backward to ins_feat + means2D (stage-1 style).
+Inputs are resident in HBM before the timed region.  value = views*W*H / time, summed over all ranks
+(weak scaling: rank r renders its own view of the same replicated scene; for N > 1 the per-Gaussian
+gradients of both passes are SUM-all-reduced over RCCL inside the step, overlapped with pass B).
+
+One JSON line on rank 0, with `roofline` (dominant kernel, HIP events on the launch stream, algorithmic
+bytes of SURVEY.md section 8(d)) and `cpu_baseline` (the CPU oracle = pure-PyTorch per-tile alpha blend,
+bounded sample, rank 0 at N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~6300 achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="S1M-1080p", choices=["S1M-1080p", "C2-100k-800"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-tile-stride", type=int, default=24, help="CPU baseline renders every k-th tile")
+    ap.add_argument("--no-kmeans", action="store_true")
+    ap.add_argument("--rgb-only", action="store_true", help="time pass A only (BASELINE.md row 'RGB')")
+    return ap.parse_args()
+
+
+WORKLOADS = {
+    "S1M-1080p": dict(P=1_000_000, W=1920, H=1080, f=1000.0),
+    "C2-100k-800": dict(P=100_000, W=800, H=800, f=700.0),
+}
+
+
+def algorithmic_bytes(P, D, npx, C, K_in, S=6):
+    """SURVEY.md section 8(d).  Returns dict of per-kernel and whole-pass algorithmic bytes."""
+    b = {}
+    b["preprocess_kernel"] = P * (44 + 4 * K_in + 52)
+    b["binning"] = D * (12 + 24 * S + 8)
+    b["blend_forward_kernel"] = D * (28 + 4 * C + 4) + npx * (4 * C + 12)
+    b["blend_backward_kernel"] = npx * (4 * C + 16) + D * (28 + 4 * C + 4) + D * 2 * (4 * C + 28)
+    b["preprocess_backward_kernel"] = P * (44 + 4 * K_in + 4 + 4 * C + 28) + P * (40 + 4 * K_in)
+    b["fwd"] = b["preprocess_kernel"] + b["binning"] + b["blend_forward_kernel"]
+    b["bwd"] = b["blend_backward_kernel"] + b["preprocess_backward_kernel"]
+    return b
+
+
+def cpu_baseline(scene, cam, W, H, f, stride, rgb_only):
+    """Pure-PyTorch CPU alpha blend (the oracle) fwd + autograd bwd on every `stride`-th tile of the same
+    scene; preprocess + binning (NumPy) are run in full and charged pro rata."""
+    import numpy as np
+    from oracle import raster_oracle as ro
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    tanx, tany = W / (2 * f), H / (2 * f)
+    t0 = time.time()
+    g = ro.preprocess(scene.means3D.numpy(), scene.opacities.numpy(), cam.world_view_transform.numpy(),
+                      cam.full_proj_transform.numpy(), cam.camera_center.numpy(), W, H, tanx, tany,
+                      scales=scene.scales.numpy(), rotations=scene.rotations.numpy(), shs=scene.shs.numpy(), sh_degree=3)
+    b = ro.bin_tiles(g, W, H)
+    t_geom = time.time() - t0
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    tiles = list(range(0, gx * gy, stride))
+    gen = torch.Generator().manual_seed(1)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    t0 = time.time()
+    passes = [(t(g.rgb), 3)] + ([] if rgb_only else [(scene.ins_feat.clone(), 6)])
+    for feats, C in passes:
+        leaves = [t(g.xy).requires_grad_(True), t(g.conic).requires_grad_(True), t(g.opacity).requires_grad_(True),
+                  feats.requires_grad_(True), t(g.depth).requires_grad_(True)]
+        color, depth, alpha, _ = ro.blend(*leaves, b.ranges, b.point_list, W, H, torch.zeros(C), tiles=tiles)
+        gC = torch.randn(color.shape, generator=gen)
+        gA = torch.randn(alpha.shape, generator=gen)
+        torch.autograd.backward([color, alpha], [gC, gA])
+    t_blend = time.time() - t0
+    frac = len(tiles) / (gx * gy)
+    px = len(tiles) * 256
+    total = t_blend + t_geom * frac
+    return {"value": px / total / 1e6, "unit": "Mpix/s", "cores": ncores, "kind": "port",
+            "sample": (f"oracle/raster_oracle.py (pure-PyTorch per-tile alpha blend fwd + autograd bwd, fp32) on every "
+                       f"{stride}th 16x16 tile of the same scene ({len(tiles)} tiles, {px} px, {t_blend:.1f} s) + NumPy "
+                       f"preprocess/binning of all {scene.means3D.shape[0]} Gaussians charged pro rata ({t_geom:.1f} s x {frac:.3f}); "
+                       f"per-Gaussian preprocess backward not included")}
+
+
+def kmeans_bench(device):
+    """k-means it/s (second half of BASELINE.json's metric): N=2M, d=9 (6 feat + 3 xyz), k=64, 5 Lloyd
+    iterations + re-assignment per call (ScanNet config C4, scene/kmeans_quantize.py:146-241)."""
+    from opengaussian_amd.kmeans import lloyd
+    g = torch.Generator().manual_seed(0)
+    N, d, k, iters = 2_000_000, 9, 64, 5
+    feat = torch.cat([torch.rand(N, 6, generator=g), torch.randn(N, 3, generator=g)], dim=1).to(device)
+    cent = feat[torch.randperm(N, generator=g)[:k].to(device)].clone()
+    for _ in range(2):
+        lloyd(feat, cent.clone(), iters=iters, nchunks=N // 10000 + 1)
+    torch.cuda.synchronize()
+    reps = 10
+    t0 = time.time()
+    for _ in range(reps):
+        lloyd(feat, cent.clone(), iters=iters, nchunks=N // 10000 + 1)
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / reps
+    bytes_iter = N * (4 * d + 8) + 8 * k * d
+    return {"it_per_s": iters / dt, "ms_per_call": dt * 1e3, "N": N, "d": d, "k": k, "iters_per_call": iters,
+            "algorithmic_GBps": bytes_iter * iters / dt / 1e9}
+
+
+_T0 = time.time()
+
+
+def log(msg):
+    """progress on stderr (the JSON line is the only thing on stdout)"""
+    sys.stderr.write(f"[bench +{time.time() - _T0:7.1f}s] {msg}\n")
+    sys.stderr.flush()
+
+
+def main():
+    args = parse()
+    log("start")
+    from opengaussian_amd import _lib, dp
+    from opengaussian_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    from opengaussian_amd.synthetic import make_scene, orbit_camera
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    rank, world, local = dp.init_from_env("cuda")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    import torch.distributed as dist
+
+    wl = WORKLOADS[args.workload]
+    P, W, H, f = wl["P"], wl["W"], wl["H"], wl["f"]
+    scene_cpu = make_scene(P, W, H, f, f, seed=0)
+    log(f"scene built: P={P} {W}x{H}")
+    cam_cpu = orbit_camera(W, H, f, f, view_index=rank, num_views=max(world, 1))
+    scene, cam = scene_cpu.to(device), cam_cpu.to(device)
+    tanx, tany = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+    settings = GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=tanx, tanfovy=tany, bg=torch.zeros(3, device=device),
+        scale_modifier=1.0, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, sh_degree=3,
+        campos=cam.camera_center, prefiltered=False, debug=False)
+    rast = GaussianRasterizer(settings)
+
+    leaves = dict(means3D=scene.means3D, scales=scene.scales, rotations=scene.rotations, opacities=scene.opacities,
+                  shs=scene.shs, ins_feat=scene.ins_feat)
+    for v in leaves.values():
+        v.requires_grad_(True)
+    gen = torch.Generator().manual_seed(100 + rank)
+    gC = torch.randn(3, H, W, generator=gen).to(device)
+    gA = torch.randn(1, H, W, generator=gen).to(device)
+    gF = torch.randn(6, H, W, generator=gen).to(device)
+
+    names_a = ["means3D", "scales", "rotations", "opacities", "shs"]
+    bucket_a = dp.GradBucket([leaves[n].shape for n in names_a], device) if world > 1 else None
+    bucket_b = dp.GradBucket([leaves["ins_feat"].shape], device) if world > 1 and not args.rgb_only else None
+    info = {}
+
+    def step():
+        for v in leaves.values():
+            v.grad = None
+        m2a = torch.zeros(P, 3, device=device, requires_grad=True)
+        color, radii, depth, alpha = rast(means3D=leaves["means3D"], means2D=m2a, opacities=leaves["opacities"],
+                                          shs=leaves["shs"], scales=leaves["scales"], rotations=leaves["rotations"])
+        info["D"] = color.grad_fn.num_rendered
+        torch.autograd.backward([color, alpha], [gC, gA])
+        if bucket_a is not None:
+            bucket_a.pack([leaves[n].grad for n in names_a])
+            bucket_a.allreduce_async()
+        if not args.rgb_only:
+            m2b = torch.zeros(P, 3, device=device, requires_grad=True)
+            feat, _, _, _ = rast(means3D=leaves["means3D"].detach(), means2D=m2b, opacities=leaves["opacities"].detach(),
+                                 colors_precomp=leaves["ins_feat"], scales=leaves["scales"].detach(),
+                                 rotations=leaves["rotations"].detach())
+            torch.autograd.backward([feat], [gF])
+            if bucket_b is not None:
+                bucket_b.pack([leaves["ins_feat"].grad])
+                bucket_b.allreduce_async()
+        if world > 1:
+            dp.reduce_densification_stats(m2a.grad, radii)
+            bucket_a.wait()
+            if bucket_b is not None:
+                bucket_b.wait()
+        return radii
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        radii = step()
+        torch.cuda.synchronize()
+        log(f"warmup step {i} done (D={info.get('D')})")
+    barrier()
+    _lib.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        radii = step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    log(f"timed region done: {elapsed / args.steps * 1e3:.3f} ms/step")
+    prof = _lib.prof_collect()
+    _lib.prof_enable(False)
+    if world > 1:
+        te = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * W * H * args.steps / elapsed / 1e6
+
+    if rank == 0:
+        D = int(info["D"])
+        npx = W * H
+        p_vis = int((radii > 0).sum().item())
+        gxy = ((W + 15) // 16) * ((H + 15) // 16)
+        per_kernel = {k: {"calls": v["calls"], "avg_ms": v["total_ms"] / max(v["calls"], 1), "total_ms": v["total_ms"]}
+                      for k, v in prof.items()}
+        dom = max(per_kernel, key=lambda k: per_kernel[k]["total_ms"])
+        dom_base = dom.split("<")[0]
+        dom_C = int(dom.split("<")[1].rstrip(">")) if "<" in dom and dom.split("<")[1].rstrip(">").isdigit() else 3
+        ab = algorithmic_bytes(P, D, npx, dom_C, 48 if dom_C == 3 else dom_C)
+        dom_bytes = ab.get(dom_base)
+        traffic = None
+        pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc_file):
+            try:
+                traffic = json.load(open(pmc_file)).get(dom)
+            except Exception:
+                traffic = None
+        roofline = None
+        if dom_bytes is not None:
+            achieved = dom_bytes / (per_kernel[dom]["avg_ms"] * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                        "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": per_kernel[dom]["avg_ms"]}
+        step_bytes = sum(algorithmic_bytes(P, D, npx, 3, 48)[k] for k in ("fwd", "bwd"))
+        if not args.rgb_only:
+            step_bytes += sum(algorithmic_bytes(P, D, npx, 6, 6)[k] for k in ("fwd", "bwd"))
+        out = {
+            "metric": "fwd+bwd Mpix/s at 1080p, 1M Gaussians (RGB+6-D ins_feat); k-means it/s",
+            "value": value, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload + (" RGB(SH3) fwd+bwd only" if args.rgb_only else
+                                                    " RGB(SH3)+depth+alpha fwd+bwd (all grads) + fused 6-ch ins_feat fwd+bwd"),
+                       "gaussians": P, "width": W, "height": H, "views_per_step": world,
+                       "parallelism": f"view-dp{world}" if world > 1 else "single"},
+            "scene": {"P_visible": p_vis, "D_num_rendered": D, "mean_tile_list": D / gxy},
+            "roofline": roofline,
+            "step_algorithmic_GBps": step_bytes / (ms_per_step * 1e-3) / 1e9,
+            "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]["total_ms"])},
+        }
+        if world == 1 and not args.no_kmeans:
+            try:
+                log("k-means bench")
+                out["kmeans"] = kmeans_bench(device)
+            except Exception as e:   # k-means is the second half of the metric, never the headline value
+                out["kmeans"] = {"error": repr(e)}
+        if world == 1 and not args.no_cpu_baseline:
+            log("cpu baseline (oracle)")
+            out["cpu_baseline"] = cpu_baseline(scene_cpu, cam_cpu, W, H, f, args.cpu_tile_stride, args.rgb_only)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

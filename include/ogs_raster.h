@@ -151,6 +151,12 @@ int ogs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, c
 int ogs_raster_export_binning(const OgsRasterFwdArgs* args, int64_t num_rendered, uint64_t* keys_out,
                               uint32_t* ranges_out, uint32_t* n_contrib_out, void* stream);
 
+/* Optional per-kernel timing with HIP events on the launch stream (used by bench.py's roofline leg;
+ * not part of the reference boundary).  enable(1) starts a fresh recording, collect() writes a JSON
+ * object {"kernel": {"calls": n, "total_ms": t}, ...} into buf (host memory). */
+int ogs_prof_enable(int on);
+int ogs_prof_collect(char* buf, size_t n);
+
 /* Test hook, not part of the reference boundary: runs the wave64 16-slot transposed reduction of the
  * backward blend on in[64][16]; out[lane] = sum over lanes of slot (lane >> 2). */
 int ogs_selftest_wave_fold16(const float* in, float* out, void* stream);

@@ -60,6 +60,8 @@ SIGNATURES = {
     "ogs_mark_visible": (C.c_int, [C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "ogs_raster_export_binning": (C.c_int, [C.POINTER(OgsRasterFwdArgs), C.c_int64, _vp, _vp, _vp, _vp]),
     "ogs_selftest_wave_fold16": (C.c_int, [_vp, _vp, _vp]),
+    "ogs_prof_enable": (C.c_int, [C.c_int]),
+    "ogs_prof_collect": (C.c_int, [C.c_char_p, C.c_size_t]),
     "ogs_kmeans_tmp_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     "ogs_kmeans_lloyd": (C.c_int, [_vp, C.c_int64, C.c_int32, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                    _vp, C.c_int64, _vp, _vp]),
@@ -93,6 +95,18 @@ def lib() -> C.CDLL:
 def check(rc: int, what: str):
     if rc != 0:
         raise OgsError(f"{what} failed (code {rc}): {lib().ogs_last_error().decode()}")
+
+
+def prof_enable(on: bool):
+    check(lib().ogs_prof_enable(1 if on else 0), "ogs_prof_enable")
+
+
+def prof_collect() -> dict:
+    """{kernel name: {"calls": n, "total_ms": t}} for launches since prof_enable(True)."""
+    import json
+    buf = C.create_string_buffer(1 << 16)
+    check(lib().ogs_prof_collect(buf, len(buf)), "ogs_prof_collect")
+    return json.loads(buf.value.decode())
 
 
 def ptr(t):

@@ -23,6 +23,8 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fhip-fp32-co
 # per-file extra flags: the forward preprocess must match the oracle's operation order bit-for-bit
 EXTRA = {
     "preprocess_fwd.hip": ["-ffp-contract=off"],
+    # k-means argmin: same sum-of-squares operation order as oracle/kmeans_oracle.py (HBM-bound, FMA buys nothing)
+    "kmeans.hip": ["-ffp-contract=off"],
 }
 
 

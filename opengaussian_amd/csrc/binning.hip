@@ -250,23 +250,23 @@ int exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out
     }
     const int nb = scan_blocks(n);
     if (nb == 1) {
-        hipLaunchKernelGGL(scan_apply_kernel, dim3(1), dim3(kBlock), 0, stream, in, gather, out, n,
+        OGS_LAUNCH(scan_apply_kernel, dim3(1), dim3(kBlock), 0, stream, in, gather, out, n,
                            (const uint32_t*)nullptr, total);
         OGS_LAUNCH_CHECK(debug, stream);
         return OGS_OK;
     }
     uint32_t* partials = static_cast<uint32_t*>(tmp);
     void* next_tmp = static_cast<char*>(tmp) + align_up((size_t)nb * sizeof(uint32_t));
-    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(kBlock), 0, stream, in, gather, n, partials);
+    OGS_LAUNCH(scan_reduce_kernel, dim3(nb), dim3(kBlock), 0, stream, in, gather, n, partials);
     OGS_LAUNCH_CHECK(debug, stream);
     int rc = exclusive_scan_u32(partials, nullptr, partials, nb, nullptr, next_tmp, stream, debug);
     if (rc != OGS_OK) return rc;
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(kBlock), 0, stream, in, gather, out, n,
+    OGS_LAUNCH(scan_apply_kernel, dim3(nb), dim3(kBlock), 0, stream, in, gather, out, n,
                        (const uint32_t*)partials, (uint32_t*)nullptr);
     OGS_LAUNCH_CHECK(debug, stream);
     if (total) {
         if (in == out) { set_error("exclusive_scan_u32: total with in-place scan unsupported"); return OGS_ERR_INVALID_ARG; }
-        hipLaunchKernelGGL(scan_total_kernel, dim3(1), dim3(64), 0, stream, in, gather, (const uint32_t*)out, n, total);
+        OGS_LAUNCH(scan_total_kernel, dim3(1), dim3(64), 0, stream, in, gather, (const uint32_t*)out, n, total);
         OGS_LAUNCH_CHECK(debug, stream);
     }
     return OGS_OK;
@@ -280,11 +280,11 @@ int radix_pass(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_
     const int ndig = 1 << bits;
     uint32_t* hist = static_cast<uint32_t*>(tmp);
     void* scan_tmp = static_cast<char*>(tmp) + align_up((size_t)256 * nb * sizeof(uint32_t));
-    hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(kBlock), 0, stream, keys_in, n, shift, bits, hist, nb);
+    OGS_LAUNCH(radix_hist_kernel, dim3(nb), dim3(kBlock), 0, stream, keys_in, n, shift, bits, hist, nb);
     OGS_LAUNCH_CHECK(debug, stream);
     int rc = exclusive_scan_u32(hist, nullptr, hist, (int64_t)ndig * nb, nullptr, scan_tmp, stream, debug);
     if (rc != OGS_OK) return rc;
-    hipLaunchKernelGGL(radix_scatter_kernel, dim3(nb), dim3(kBlock), 0, stream, keys_in, vals_in, keys_out, vals_out, n,
+    OGS_LAUNCH(radix_scatter_kernel, dim3(nb), dim3(kBlock), 0, stream, keys_in, vals_in, keys_out, vals_out, n,
                        shift, bits, (const uint32_t*)hist, nb);
     OGS_LAUNCH_CHECK(debug, stream);
     return OGS_OK;
@@ -295,14 +295,14 @@ int launch_tile_ranges(const uint32_t* tile_keys_sorted, int64_t D, uint2* range
     OGS_HIP_CHECK(hipMemsetAsync(ranges, 0, (size_t)tiles * sizeof(uint2), s));
     if (D <= 0) return OGS_OK;
     const int grid = (int)((D + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3(grid), dim3(kBlock), 0, s, tile_keys_sorted, D, ranges);
+    OGS_LAUNCH(tile_ranges_kernel, dim3(grid), dim3(kBlock), 0, s, tile_keys_sorted, D, ranges);
     OGS_LAUNCH_CHECK(debug, s);
     return OGS_OK;
 }
 
 int launch_export_keys(const uint2* ranges, int tiles, const uint32_t* point_list, const float4* rec, int recv4,
                        uint64_t* keys_out, hipStream_t s) {
-    hipLaunchKernelGGL(export_keys_kernel, dim3(tiles), dim3(kBlock), 0, s, ranges, point_list, rec, recv4, keys_out);
+    OGS_LAUNCH(export_keys_kernel, dim3(tiles), dim3(kBlock), 0, s, ranges, point_list, rec, recv4, keys_out);
     OGS_LAUNCH_CHECK(0, s);
     return OGS_OK;
 }

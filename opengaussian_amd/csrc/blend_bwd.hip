@@ -227,7 +227,8 @@ __global__ void wave_fold16_test_kernel(const float* __restrict__ in, float* __r
 template <int C>
 int launch_c(const OgsRasterBwdArgs& a, const GeomState& gs, const ImageState& is, float* grad_rec, hipStream_t s) {
     const int gx = (a.W + kTile - 1) / kTile, gy = (a.H + kTile - 1) / kTile;
-    hipLaunchKernelGGL(blend_backward_kernel<C>, dim3(gx * gy), dim3(kBlock), 0, s, (const uint2*)is.ranges,
+    static constexpr const char* const kNames[4] = {"blend_backward_kernel<3>", "blend_backward_kernel<6>", "blend_backward_kernel<9>", "blend_backward_kernel<12>"};
+    OGS_LAUNCH_NAMED(chan_name<C>(kNames), blend_backward_kernel<C>, dim3(gx * gy), dim3(kBlock), 0, s, (const uint2*)is.ranges,
                        a.point_list, a.W, a.H, gx, (const float4*)gs.rec, a.bg, a.out_alpha,
                        (const uint32_t*)is.n_contrib, a.dL_dcolor, a.dL_ddepth, a.dL_dalpha, grad_rec);
     OGS_LAUNCH_CHECK(a.debug, s);
@@ -248,7 +249,7 @@ int launch_blend_backward(const OgsRasterBwdArgs& a, const GeomState& gs, const 
 }
 
 int launch_wave_fold16_test(const float* in, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(wave_fold16_test_kernel, dim3(1), dim3(kWave), 0, s, in, out);
+    OGS_LAUNCH(wave_fold16_test_kernel, dim3(1), dim3(kWave), 0, s, in, out);
     OGS_LAUNCH_CHECK(1, s);
     return OGS_OK;
 }

@@ -129,7 +129,8 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
 template <int C>
 int launch_c(const OgsRasterFwdArgs& a, const GeomState& gs, const ImageState& is, hipStream_t s) {
     const int gx = (a.W + kTile - 1) / kTile, gy = (a.H + kTile - 1) / kTile;
-    hipLaunchKernelGGL(blend_forward_kernel<C>, dim3(gx * gy), dim3(kBlock), 0, s, (const uint2*)is.ranges,
+    static constexpr const char* const kNames[4] = {"blend_forward_kernel<3>", "blend_forward_kernel<6>", "blend_forward_kernel<9>", "blend_forward_kernel<12>"};
+    OGS_LAUNCH_NAMED(chan_name<C>(kNames), blend_forward_kernel<C>, dim3(gx * gy), dim3(kBlock), 0, s, (const uint2*)is.ranges,
                        (const uint32_t*)a.point_list, a.W, a.H, gx, (const float4*)gs.rec, a.bg, a.out_color,
                        a.out_depth, a.out_alpha, is.n_contrib);
     OGS_LAUNCH_CHECK(a.debug, s);

@@ -3,6 +3,11 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
 #include "ogs_common.h"
 
 namespace ogs {
@@ -14,6 +19,35 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+// ---- per-kernel timing ----------------------------------------------------------------------------------
+namespace {
+struct ProfRec { const char* name; hipEvent_t start, stop; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+std::vector<hipEvent_t> g_event_pool;
+std::mutex g_prof_mu;
+hipEvent_t take_event() {
+    if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+}  // namespace
+
+ProfScope::ProfScope(const char* n, hipStream_t s) : name(n), stream(s), slot(-1) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfRec r{n, take_event(), take_event()};
+    (void)hipEventRecord(r.start, s);
+    g_prof.push_back(r);
+    slot = (int)g_prof.size() - 1;
+}
+ProfScope::~ProfScope() {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    (void)hipEventRecord(g_prof[slot].stop, stream);
 }
 
 static int bit_length(uint32_t v) {
@@ -55,6 +89,45 @@ using namespace ogs;
 extern "C" {
 
 int ogs_version(void) { return 100; }
+
+/* Per-kernel timing with HIP events recorded on the launch stream (bench.py's `roofline` leg).
+ * ogs_prof_enable(1) starts a fresh recording; ogs_prof_collect() waits for the recorded events and
+ * writes a JSON object {"kernel": {"calls": n, "total_ms": t}, ...} into buf. */
+int ogs_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : g_prof) { g_event_pool.push_back(r.start); g_event_pool.push_back(r.stop); }
+    g_prof.clear();
+    g_prof_on = on != 0;
+    return OGS_OK;
+}
+
+int ogs_prof_collect(char* buf, size_t n) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    std::map<std::string, std::pair<long, double>> agg;
+    for (auto& r : g_prof) {
+        OGS_HIP_CHECK(hipEventSynchronize(r.stop));
+        float ms = 0.f;
+        OGS_HIP_CHECK(hipEventElapsedTime(&ms, r.start, r.stop));
+        auto& a = agg[r.name];
+        a.first += 1;
+        a.second += ms;
+    }
+    std::string out = "{";
+    bool first = true;
+    for (auto& kv : agg) {
+        char line[384];
+        std::string nm = kv.first;
+        for (auto& ch : nm) if (ch == '"') ch = '\'';
+        snprintf(line, sizeof(line), "%s\"%s\": {\"calls\": %ld, \"total_ms\": %.6f}", first ? "" : ", ", nm.c_str(),
+                 kv.second.first, kv.second.second);
+        out += line;
+        first = false;
+    }
+    out += "}";
+    if (!buf || out.size() + 1 > n) { set_error("prof_collect: buffer too small (%zu needed)", out.size() + 1); return OGS_ERR_SCRATCH_TOO_SMALL; }
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return OGS_OK;
+}
 const char* ogs_last_error(void) { return g_err; }
 
 size_t ogs_raster_geom_bytes(int32_t P, int32_t C) { return GeomState::bytes(P > 0 ? P : 1, C); }

@@ -163,7 +163,7 @@ int ogs_kmeans_assign(const float* feat, int64_t N, int32_t d, const float* cent
     hipStream_t s = static_cast<hipStream_t>(stream_);
     rc = allow_lds(kmeans_pass_kernel<false, true>, pass_lds(d, k, false));
     if (rc != OGS_OK) return rc;
-    hipLaunchKernelGGL((kmeans_pass_kernel<false, true>), dim3(pass_blocks(N)), dim3(kBlock), pass_lds(d, k, false), s, feat,
+    OGS_LAUNCH((kmeans_pass_kernel<false, true>), dim3(pass_blocks(N)), dim3(kBlock), pass_lds(d, k, false), s, feat,
                        N, d, centers, k, k, ids_out, id_offset, (float*)nullptr);
     OGS_LAUNCH_CHECK(0, s);
     return OGS_OK;
@@ -186,18 +186,18 @@ int ogs_kmeans_lloyd(const float* feat, int64_t N, int32_t d, float* centers, in
     if (rc != OGS_OK) return rc;
     float* partials = static_cast<float*>(tmp);
     float* counts = reinterpret_cast<float*>(static_cast<char*>(tmp) + align_up((size_t)nb * k * (d + 1) * sizeof(float)));
-    hipLaunchKernelGGL(fill_kernel, dim3((k + kBlock - 1) / kBlock), dim3(kBlock), 0, s, counts, k, 1e-6f);
+    OGS_LAUNCH(fill_kernel, dim3((k + kBlock - 1) / kBlock), dim3(kBlock), 0, s, counts, k, 1e-6f);
     OGS_LAUNCH_CHECK(0, s);
     for (int it = 0; it < iters; ++it) {
-        hipLaunchKernelGGL((kmeans_pass_kernel<true, false>), dim3(nb), dim3(kBlock), pass_lds(d, k, true), s, feat, N, d,
+        OGS_LAUNCH((kmeans_pass_kernel<true, false>), dim3(nb), dim3(kBlock), pass_lds(d, k, true), s, feat, N, d,
                            (const float*)centers, k, k_active, (int64_t*)nullptr, (int64_t)0, partials);
         OGS_LAUNCH_CHECK(0, s);
-        hipLaunchKernelGGL(kmeans_finalize_kernel, dim3((k + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
+        OGS_LAUNCH(kmeans_finalize_kernel, dim3((k + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
                            (const float*)partials, nb, k, d, (float)nchunks * 1e-6f, counts, centers);
         OGS_LAUNCH_CHECK(0, s);
     }
     if (N > 0) {
-        hipLaunchKernelGGL((kmeans_pass_kernel<false, true>), dim3(nb), dim3(kBlock), pass_lds(d, k, false), s, feat, N, d,
+        OGS_LAUNCH((kmeans_pass_kernel<false, true>), dim3(nb), dim3(kBlock), pass_lds(d, k, false), s, feat, N, d,
                            (const float*)centers, k, k_active, ids_out, id_offset, (float*)nullptr);
         OGS_LAUNCH_CHECK(0, s);
     }
@@ -210,7 +210,7 @@ int ogs_kmeans_gather(const float* centers, const int64_t* ids, int64_t N, int32
     if (!centers || !ids || !out || out_dim < 1 || out_dim > vec_dim) { set_error("kmeans_gather: bad arguments"); return OGS_ERR_INVALID_ARG; }
     hipStream_t s = static_cast<hipStream_t>(stream_);
     const int64_t total = N * out_dim;
-    hipLaunchKernelGGL(kmeans_gather_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, centers, ids,
+    OGS_LAUNCH(kmeans_gather_kernel, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, centers, ids,
                        N, vec_dim, out_dim, out);
     OGS_LAUNCH_CHECK(0, s);
     return OGS_OK;

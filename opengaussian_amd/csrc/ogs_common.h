@@ -35,6 +35,31 @@ void set_error(const char* fmt, ...);
         if (debug) OGS_HIP_CHECK(hipStreamSynchronize(stream));                          \
     } while (0)
 
+// ---- optional per-kernel timing (HIP events on the launch stream; used by bench.py) -----------------
+struct ProfScope {
+    const char* name;
+    hipStream_t stream;
+    int slot;
+    ProfScope(const char* name, hipStream_t s);
+    ~ProfScope();
+};
+#define OGS_LAUNCH(kernel, grid, block, lds, stream, ...)                      \
+    do {                                                                       \
+        ogs::ProfScope _ps(#kernel, stream);                                   \
+        hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);     \
+    } while (0)
+
+// same, with an explicit timing name (template kernels: one name per channel count)
+#define OGS_LAUNCH_NAMED(name, kernel, grid, block, lds, stream, ...)          \
+    do {                                                                       \
+        ogs::ProfScope _ps(name, stream);                                      \
+        hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);     \
+    } while (0)
+template <int C>
+constexpr const char* chan_name(const char* const (&names)[4]) {
+    return C == 3 ? names[0] : C == 6 ? names[1] : C == 9 ? names[2] : names[3];
+}
+
 // ---- scratch carving ------------------------------------------------------------------------
 constexpr size_t kAlign = 256;
 inline size_t align_up(size_t v, size_t a = kAlign) { return (v + a - 1) / a * a; }

@@ -277,7 +277,8 @@ int launch_c(const OgsRasterBwdArgs& a, const GeomState& gs, const float* grad_r
     const float focal_x = (float)a.W / (2.0f * a.tanfovx);
     const float focal_y = (float)a.H / (2.0f * a.tanfovy);
     const int grid = (a.P + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(preprocess_backward_kernel<C>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, a.sh_degree,
+    static constexpr const char* const kNames[4] = {"preprocess_backward_kernel<3>", "preprocess_backward_kernel<6>", "preprocess_backward_kernel<9>", "preprocess_backward_kernel<12>"};
+    OGS_LAUNCH_NAMED(chan_name<C>(kNames), preprocess_backward_kernel<C>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, a.sh_degree,
                        a.sh_coeffs, a.tanfovx, a.tanfovy, focal_x, focal_y, a.scale_modifier, a.means3D, a.shs, a.scales,
                        a.rotations, a.cov3D_precomp, a.viewmatrix, a.projmatrix, a.campos, a.radii,
                        (const uint32_t*)gs.clamped, grad_rec, a.dL_dmeans2D, a.dL_dcolors, a.dL_dopacity, a.dL_dmeans3D,

@@ -286,7 +286,8 @@ int launch_preprocess_c(const OgsRasterFwdArgs& a, const GeomState& gs, const Ge
     const float focal_x = (float)a.W / (2.0f * a.tanfovx);
     const float focal_y = (float)a.H / (2.0f * a.tanfovy);
     const int grid = (a.P + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(preprocess_kernel<C>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, a.sh_degree, a.sh_coeffs,
+    static constexpr const char* const kNames[4] = {"preprocess_kernel<3>", "preprocess_kernel<6>", "preprocess_kernel<9>", "preprocess_kernel<12>"};
+    OGS_LAUNCH_NAMED(chan_name<C>(kNames), preprocess_kernel<C>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, a.sh_degree, a.sh_coeffs,
                        a.tanfovx, a.tanfovy, focal_x, focal_y, a.scale_modifier, a.means3D, a.colors_precomp, a.shs,
                        a.opacities, a.scales, a.rotations, a.cov3D_precomp, a.viewmatrix, a.projmatrix, a.campos,
                        gs.rec, gs.clamped, a.radii, gt.tiles_touched, gt.keys[0], gt.order[0]);
@@ -310,9 +311,9 @@ int launch_duplicate(const OgsRasterFwdArgs& a, const GeomState& gs, const GeomT
                      uint32_t* vals, hipStream_t s) {
     const int grid = (a.P + kBlock - 1) / kBlock;
     switch (rec_vec4(a.C)) {
-        case 3: hipLaunchKernelGGL(duplicate_kernel<3>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals); break;
-        case 4: hipLaunchKernelGGL(duplicate_kernel<4>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals); break;
-        case 5: hipLaunchKernelGGL(duplicate_kernel<5>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals); break;
+        case 3: OGS_LAUNCH(duplicate_kernel<3>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals); break;
+        case 4: OGS_LAUNCH(duplicate_kernel<4>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals); break;
+        case 5: OGS_LAUNCH(duplicate_kernel<5>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals); break;
         default: set_error("unsupported record size"); return OGS_ERR_UNSUPPORTED;
     }
     OGS_LAUNCH_CHECK(a.debug, s);
@@ -321,7 +322,7 @@ int launch_duplicate(const OgsRasterFwdArgs& a, const GeomState& gs, const GeomT
 
 int launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s) {
     const int grid = (P + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(mark_visible_kernel, dim3(grid), dim3(kBlock), 0, s, P, means3D, viewmatrix, present);
+    OGS_LAUNCH(mark_visible_kernel, dim3(grid), dim3(kBlock), 0, s, P, means3D, viewmatrix, present);
     OGS_LAUNCH_CHECK(0, s);
     return OGS_OK;
 }

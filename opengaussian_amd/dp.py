@@ -1,0 +1,108 @@
+"""One-view-per-GPU data parallelism for the rasterizer path (new capability; the reference is
+single-process).
+
+One process per GPU (torch.distributed, backend "nccl" == RCCL over xGMI on ROCm; "gloo" on CPU for the
+tests).  Gaussians are replicated; rank r renders view r of the mini-batch; the only exchange per step is
+  * SUM all-reduce of the flattened per-Gaussian gradients (one flat bucket -> few, large collectives,
+    which is what point-to-point xGMI links want), issued asynchronously so it overlaps the next pass;
+  * the non-linear densification statistics, which cannot be recovered from summed gradients
+    (scene/gaussian_model.py:512-514, train.py:597): SUM of per-view ||grad means2D[:, :2]||, SUM of
+    visibility counts, MAX of radii.
+The partition has no data-path collective: views are independent (weak scaling).
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(device_type: str = "cuda") -> tuple[int, int, int]:
+    """(rank, world_size, local_rank) from torchrun's env; initialises the default group if needed."""
+    import os
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = "nccl" if device_type == "cuda" else "gloo"
+        if device_type == "cuda":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+class GradBucket:
+    """Flat fp32 buffer holding a fixed list of per-Gaussian gradient tensors, all-reduced as ONE message."""
+
+    def __init__(self, shapes: Sequence[Sequence[int]], device, group=None, average: bool = True):
+        self.shapes = [tuple(s) for s in shapes]
+        self.sizes = [int(torch.Size(s).numel()) for s in self.shapes]
+        self.flat = torch.zeros(sum(self.sizes), dtype=torch.float32, device=device)
+        self.group = group
+        self.average = average
+        self._work = None
+        self._stream = torch.cuda.Stream(device) if torch.device(device).type == "cuda" else None
+
+    def views(self) -> List[torch.Tensor]:
+        out, off = [], 0
+        for s, n in zip(self.shapes, self.sizes):
+            out.append(self.flat[off:off + n].view(s))
+            off += n
+        return out
+
+    def pack(self, grads: Iterable[Optional[torch.Tensor]]):
+        for v, g in zip(self.views(), grads):
+            if g is None:
+                v.zero_()
+            else:
+                v.copy_(g.reshape(v.shape))
+
+    def allreduce_async(self):
+        """Start the SUM all-reduce on a side stream (overlaps whatever the caller enqueues next)."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+            return
+        if self._stream is not None:
+            self._stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._stream):
+                self._work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            self._work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def wait(self) -> List[torch.Tensor]:
+        if self._work is not None:
+            self._work.wait()
+            if self._stream is not None:
+                torch.cuda.current_stream().wait_stream(self._stream)
+            self._work = None
+            if self.average:
+                self.flat.div_(dist.get_world_size(self.group))
+        return self.views()
+
+
+def reduce_densification_stats(grad_means2D: torch.Tensor, radii: torch.Tensor, group=None):
+    """Per-view statistics that must be reduced separately from the gradients.
+
+    Returns (sum over views of ||grad_means2D[:, :2]|| * visible, visibility count, max radii), i.e. what
+    add_densification_stats (scene/gaussian_model.py:512-514) and max_radii2D (train.py:597) would have
+    accumulated had the views been processed one after another."""
+    vis = radii > 0
+    norm = torch.norm(grad_means2D[:, :2], dim=-1) * vis
+    cnt = vis.to(torch.float32)
+    rmax = radii.to(torch.int32).clone()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        packed = torch.stack([norm, cnt])
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+        norm, cnt = packed[0], packed[1]
+        dist.all_reduce(rmax, op=dist.ReduceOp.MAX, group=group)
+    return norm, cnt, rmax
+
+
+def shard_views(num_views: int, rank: int, world: int) -> List[int]:
+    """Views rendered by `rank` for a mini-batch of `num_views` (round-robin, one view per GPU per step
+    when num_views == world)."""
+    return [v for v in range(num_views) if v % world == rank]

@@ -1,0 +1,87 @@
+"""CPU, world_size 2 over gloo: the one-view-per-GPU exchange (gradient bucket all-reduce, densification
+statistics) and the view sharding logic."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from opengaussian_amd import dp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    r, w, _ = dp.init_from_env("cpu")
+    assert (r, w) == (rank, world)
+    P = 37
+    shapes = [(P, 3), (P, 16, 3), (P, 1)]
+    bucket = dp.GradBucket(shapes, "cpu", average=True)
+    g = torch.Generator().manual_seed(rank)
+    grads = [torch.randn(*s, generator=g) for s in shapes]
+    grads[2] = None                         # a family without gradient must contribute zeros
+    bucket.pack(grads)
+    bucket.allreduce_async()
+    out = bucket.wait()
+    # expected: mean over ranks
+    exp = []
+    for i, s in enumerate(shapes):
+        acc = torch.zeros(*s)
+        for rr in range(world):
+            gg = torch.Generator().manual_seed(rr)
+            gs = [torch.randn(*t, generator=gg) for t in shapes]
+            if i != 2:
+                acc += gs[i]
+        exp.append(acc / world)
+    ok = all(torch.allclose(a, b, atol=1e-6) for a, b in zip(out, exp))
+    # densification statistics: SUM of norms / counts, MAX of radii
+    m2 = torch.zeros(P, 3); m2[:, 0] = rank + 1.0
+    radii = torch.arange(P, dtype=torch.int32) * (rank + 1) % 7
+    norm, cnt, rmax = dp.reduce_densification_stats(m2, radii)
+    exp_norm = sum((rr + 1.0) * ((torch.arange(P) * (rr + 1) % 7) > 0).float() for rr in range(world))
+    exp_cnt = sum(((torch.arange(P) * (rr + 1) % 7) > 0).float() for rr in range(world))
+    exp_max = torch.stack([(torch.arange(P) * (rr + 1) % 7) for rr in range(world)]).max(0)[0].to(torch.int32)
+    ok = ok and torch.allclose(norm, exp_norm) and torch.allclose(cnt, exp_cnt) and torch.equal(rmax, exp_max)
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_bucket_and_stats_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_single_process_bucket_is_identity():
+    b = dp.GradBucket([(5, 3), (5,)], "cpu")
+    g = [torch.arange(15.0).view(5, 3), torch.ones(5)]
+    b.pack(g)
+    b.allreduce_async()
+    out = b.wait()
+    assert torch.equal(out[0], g[0]) and torch.equal(out[1], g[1])
+
+
+def test_shard_views():
+    assert dp.shard_views(8, 3, 8) == [3]
+    assert dp.shard_views(8, 1, 2) == [1, 3, 5, 7]
+    assert sorted(sum((dp.shard_views(5, r, 4) for r in range(4)), [])) == list(range(5))
