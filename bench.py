@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--cpu-tile-stride", type=int, default=24, help="CPU baseline renders every k-th tile")
     ap.add_argument("--no-kmeans", action="store_true")
     ap.add_argument("--rgb-only", action="store_true", help="time pass A only (BASELINE.md row 'RGB')")
+    ap.add_argument("--separate-passes", action="store_true",
+                    help="render RGB and the 6-ch ins_feat map as two rasterizer passes (reference structure) "
+                         "instead of the single fused 9-channel pass")
     return ap.parse_args()
 
 
@@ -141,7 +144,7 @@ def main():
     args = parse()
     log("start")
     from opengaussian_amd import _lib, dp
-    from opengaussian_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    from opengaussian_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_fused
     from opengaussian_amd.synthetic import make_scene, orbit_camera
 
     if not torch.cuda.is_available():
@@ -180,7 +183,32 @@ def main():
     bucket_b = dp.GradBucket([leaves["ins_feat"].shape], device) if world > 1 and not args.rgb_only else None
     info = {}
 
+    names_f = names_a + ["ins_feat"]
+    fused = not (args.separate_passes or args.rgb_only)
+    bucket_f = dp.GradBucket([leaves[n].shape for n in names_f], device) if world > 1 and fused else None
+    gCF = torch.cat([gC, gF])
+
+    def step_fused():
+        """ONE rasterization pass: RGB (SH) in channels 0..2, ins_feat in 3..8; the feature loss is detached
+        from geometry inside the backward kernel -> same gradients as the two passes of step()."""
+        for v in leaves.values():
+            v.grad = None
+        m2 = torch.zeros(P, 3, device=device, requires_grad=True)
+        color, radii, depth, alpha = rasterize_fused(leaves["means3D"], m2, leaves["opacities"], leaves["shs"],
+                                                     leaves["ins_feat"], settings, scales=leaves["scales"],
+                                                     rotations=leaves["rotations"])
+        info["D"] = color.grad_fn.num_rendered
+        torch.autograd.backward([color, alpha], [gCF, gA])
+        if bucket_f is not None:
+            bucket_f.pack([leaves[n].grad for n in names_f])
+            bucket_f.allreduce_async()
+            dp.reduce_densification_stats(m2.grad, radii)
+            bucket_f.wait()
+        return radii
+
     def step():
+        if fused:
+            return step_fused()
         for v in leaves.values():
             v.grad = None
         m2a = torch.zeros(P, 3, device=device, requires_grad=True)
@@ -245,7 +273,7 @@ def main():
         dom = max(per_kernel, key=lambda k: per_kernel[k]["total_ms"])
         dom_base = dom.split("<")[0]
         dom_C = int(dom.split("<")[1].rstrip(">")) if "<" in dom and dom.split("<")[1].rstrip(">").isdigit() else 3
-        ab = algorithmic_bytes(P, D, npx, dom_C, 48 if dom_C == 3 else dom_C)
+        ab = algorithmic_bytes(P, D, npx, dom_C, {3: 48, 9: 54}.get(dom_C, dom_C))
         dom_bytes = ab.get(dom_base)
         traffic = None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -261,7 +289,9 @@ def main():
                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": per_kernel[dom]["avg_ms"]}
         step_bytes = sum(algorithmic_bytes(P, D, npx, 3, 48)[k] for k in ("fwd", "bwd"))
-        if not args.rgb_only:
+        if fused:
+            step_bytes = sum(algorithmic_bytes(P, D, npx, 9, 54)[k] for k in ("fwd", "bwd"))
+        elif not args.rgb_only:
             step_bytes += sum(algorithmic_bytes(P, D, npx, 6, 6)[k] for k in ("fwd", "bwd"))
         out = {
             "metric": "fwd+bwd Mpix/s at 1080p, 1M Gaussians (RGB+6-D ins_feat); k-means it/s",
@@ -269,7 +299,8 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload + (" RGB(SH3) fwd+bwd only" if args.rgb_only else
-                                                    " RGB(SH3)+depth+alpha fwd+bwd (all grads) + fused 6-ch ins_feat fwd+bwd"),
+                                                    (" RGB(SH3)+depth+alpha (all grads) + 6-ch ins_feat (grad to ins_feat) fwd+bwd, " +
+                                                     ("ONE fused 9-channel pass" if fused else "two passes (3ch SH + 6ch)"))),
                        "gaussians": P, "width": W, "height": H, "views_per_step": world,
                        "parallelism": f"view-dp{world}" if world > 1 else "single"},
             "scene": {"P_visible": p_vis, "D_num_rendered": D, "mean_tile_list": D / gxy},

@@ -60,8 +60,9 @@ typedef struct OgsRasterFwdArgs {
     int32_t debug;           /* !=0: synchronise + check after every kernel */
     const float* bg;             /* [C] */
     const float* means3D;        /* [P,3] */
-    const float* colors_precomp; /* [P,C] or NULL */
-    const float* shs;            /* [P,M,3] or NULL (requires C == 3) */
+    const float* colors_precomp; /* shs == NULL: [P,C] all blended channels.
+                                    shs != NULL and C > 3 (fused pass): [P,C-3] extra channels 3..C-1 */
+    const float* shs;            /* [P,M,3] or NULL; fills channels 0..2 (C == 3, or C > 3 with extra channels) */
     const float* opacities;      /* [P] */
     const float* scales;         /* [P,3] or NULL */
     const float* rotations;      /* [P,4] or NULL */
@@ -78,6 +79,8 @@ typedef struct OgsRasterFwdArgs {
     void* image_buffer;          /* ogs_raster_image_bytes(W, H): kept until backward */
     uint32_t* point_list;        /* [num_rendered] sorted Gaussian ids: kept until backward (render phase) */
     void* binning_tmp;           /* ogs_raster_binning_tmp_bytes(num_rendered, W, H) (render phase) */
+    void* sorted_rec;            /* ogs_raster_sorted_bytes(num_rendered, C): packed per-tile record stream the
+                                    blend kernels read through the scalar path; kept until backward */
 } OgsRasterFwdArgs;
 
 /* Arguments of the backward pass.  Mirrors upstream rasterize_gaussians_backward(bg, means3D,
@@ -90,6 +93,9 @@ typedef struct OgsRasterBwdArgs {
     float tanfovx, tanfovy, scale_modifier;
     int32_t debug;
     int32_t num_rendered;
+    int32_t geom_channels;       /* 0 or C: every channel feeds the geometry/opacity gradients (reference
+                                    behaviour).  0 < g < C: only channels [0,g) + depth + alpha do; channels
+                                    >= g just receive dL/dfeature (fused RGB + detached ins_feat pass) */
     const float* bg;
     const float* means3D;
     const float* colors_precomp;
@@ -109,9 +115,10 @@ typedef struct OgsRasterBwdArgs {
     const void* geom_buffer;
     const void* image_buffer;
     const uint32_t* point_list;
+    const void* sorted_rec;      /* from forward */
     void* bwd_tmp;               /* ogs_raster_backward_tmp_bytes(P): zeroed by the call */
     float* dL_dmeans2D;          /* [P,3] (x,y in NDC units: pixel gradient * 0.5*W / 0.5*H; z = 0) */
-    float* dL_dcolors;           /* [P,C]   (when colors_precomp was the input) */
+    float* dL_dcolors;           /* same shape as colors_precomp: [P,C], or [P,C-3] in a fused SH pass */
     float* dL_dopacity;          /* [P] */
     float* dL_dmeans3D;          /* [P,3] */
     float* dL_dcov3D;            /* [P,6]   (when cov3D_precomp was the input) */
@@ -128,6 +135,7 @@ size_t ogs_raster_geom_tmp_bytes(int32_t P);
 size_t ogs_raster_image_bytes(int32_t W, int32_t H);
 size_t ogs_raster_binning_tmp_bytes(int64_t num_rendered, int32_t W, int32_t H);
 size_t ogs_raster_backward_tmp_bytes(int32_t P);
+size_t ogs_raster_sorted_bytes(int64_t num_rendered, int32_t C);
 
 /* Phase 1: fills radii + geom_buffer, leaves the depth order and tile offsets in geom_tmp, writes
  * num_rendered to *num_rendered_host (host memory) and returns after the stream has finished it

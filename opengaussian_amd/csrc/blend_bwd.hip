@@ -1,16 +1,22 @@
-// Backward alpha blend for gfx950.
+// Backward alpha blend for gfx950 -- scalar-path design (see blend_fwd.hip).
 //
-// Same tile / quadrant / double-buffered LDS staging as the forward kernel, walking the tile list
-// BACK-TO-FRONT from the last contributor of the tile.  Per (pixel, Gaussian) the C+7 partial
-// gradients are NOT sent to memory one float atomic each (the reference's ~10 atomics per pair):
-// the 64 lanes of a wave hold a 16-slot vector each, which is folded with a transposed butterfly
+// One workgroup per 16x16 tile, each wave64 owns an 8x8 quadrant and walks the packed per-tile stream
+// BACK-TO-FRONT from its own last contributor with wave-uniform scalar loads: no LDS, no barriers.
+// Per (pixel, Gaussian) the C+7 partial gradients are NOT sent to memory one float atomic each (the
+// reference's ~10 atomics per pair): the 64 lanes hold a 16-slot vector each, folded with a transposed
+// butterfly
 //     v_permlane32_swap (xor 32) -> v_permlane16_swap (xor 16) -> DPP row_ror:8 -> row_half_mirror
 //     -> two quad_perm adds
-// (~35 VALU for all 16 slots instead of 16 x 6 shuffle-adds) so that lane 4*s ends up with the wave
-// total of slot s.  One global_atomic_add_f32 wave-instruction with <=16 active lanes then adds the
-// whole 64-byte gradient record of the Gaussian: one contiguous atomic segment per (Gaussian, wave),
-// the shape MI355X's memory-side float atomics run fastest on.  The reduction is skipped for the
-// whole wave when a ballot shows no lane received a contribution.
+// (~35 VALU for all 16 slots instead of 16 x 6 shuffle-adds) so that lane 4*s ends up with the wave total
+// of slot s.  One global_atomic_add_f32 wave-instruction with <=16 active lanes then adds the whole
+// 64-byte gradient record of the Gaussian: one contiguous atomic segment per (Gaussian, wave), the shape
+// MI355X's memory-side float atomics run fastest on.  The fold is skipped for the whole wave when a
+// ballot shows no lane received a contribution.
+//
+// `geom_channels` (<= C): only feature channels [0, geom_channels) plus depth and alpha feed dL/dalpha,
+// i.e. the geometry / opacity gradients; channels beyond it only receive their own dL/dfeature.  This is
+// what lets ONE fused pass reproduce "RGB loss reaches geometry, ins_feat loss is detached from it"
+// (train.py:431-436) exactly as two separate reference passes would.
 #include "ogs_common.h"
 
 namespace ogs {
@@ -18,7 +24,6 @@ namespace ogs {
 namespace {
 
 constexpr float kAlphaMin = 1.0f / 255.0f;
-constexpr float kThrMargin = 0.01f;
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float src) {
@@ -65,21 +70,17 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 
 template <int C>
 __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx,
-    const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ out_alpha,
-    const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth,
-    const float* __restrict__ dL_dalpha_map, float* __restrict__ grad_rec) {
-    constexpr int NV = rec_vec4(C);
-    constexpr int NF = NV - 2;
+    const uint2* __restrict__ ranges, const float* __restrict__ stream, int W, int H, int gx, int geom_channels,
+    const float* __restrict__ bg, const float* __restrict__ out_alpha, const uint32_t* __restrict__ n_contrib,
+    const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha_map,
+    float* __restrict__ grad_rec) {
+    constexpr int RS = stream_vec4(C) * 4;
     constexpr int GS = grad_stride(C);
     static_assert(C + 7 <= 16, "gradient record must fit 16 slots");
-    __shared__ float4 stage[2][kBlock * NV];
-    __shared__ uint32_t stage_id[2][kBlock];
-    __shared__ int wave_hi[kBlock / kWave];
 
     const int tile = blockIdx.x;
     const int tx = tile % gx, ty = tile / gx;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int px = tx * kTile + (wave & 1) * 8 + (lane & 7);
     const int py = ty * kTile + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = px < W && py < H;
@@ -89,12 +90,9 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
 
     const uint2 range = ranges[tile];
     const int last_contrib = inside ? (int)n_contrib[pix] : 0;
-    const int my_wave_hi = wave_max_i32(last_contrib);
-    if (lane == 0) wave_hi[wave] = my_wave_hi;
-    __syncthreads();
-    const int hi = max(max(wave_hi[0], wave_hi[1]), max(wave_hi[2], wave_hi[3]));
-    if (hi == 0) return;
-    const int rounds = (hi + kBlock - 1) / kBlock;
+    const int hi = __builtin_amdgcn_readfirstlane(wave_max_i32(last_contrib));
+    if (hi == 0) return;                                 // wave-uniform; no barriers in this kernel
+    const float* __restrict__ base = stream + (size_t)range.x * RS;
 
     const float T_final = inside ? 1.0f - out_alpha[pix] : 0.f;
     float T = T_final;
@@ -103,7 +101,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         g[c] = inside ? dL_dcolor[c * plane + pix] : 0.f;
-        bg_dot += bg[c] * g[c];
+        if (c < geom_channels) bg_dot += bg[c] * g[c];
     }
     const float gd = (inside && dL_ddepth) ? dL_ddepth[pix] : 0.f;
     const float ga = (inside && dL_dalpha_map) ? dL_dalpha_map[pix] : 0.f;
@@ -113,105 +111,75 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     float Rd = 0.f, Ra = 0.f;
     const float halfW = 0.5f * (float)W, halfH = 0.5f * (float)H;
 
-    float4 pre[NV];
-    uint32_t pre_id = 0;
-    // slot `tid` of round r holds list entry  hi-1 - r*256 - tid  (descending)
-    auto gather = [&](int r) {
-        const int i = hi - 1 - r * kBlock - tid;
-        if (i >= 0) {
-            pre_id = point_list[range.x + i];
-            const float4* src = rec + (size_t)pre_id * NV;
-#pragma unroll
-            for (int k = 0; k < NV; ++k) pre[k] = src[k];
-        }
-    };
-    gather(0);
+    // software pipeline: request entry idx-1 (s_load_dwordx8, wave-uniform) before consuming entry idx
+    StreamRec<C> nrec;
+    nrec.load(base + (size_t)(hi - 1) * RS);
+    for (int idx = hi - 1; idx >= 0; --idx) {
+        const float* __restrict__ r = base + (size_t)idx * RS;     // wave-uniform -> scalar loads
+        const StreamRec<C> rec_j = nrec;
+        const f8 cur = rec_j.g;
+        if (idx > 0) nrec.load(r - RS);
+        const float gx_ = cur[0], gy_ = cur[1], a2 = cur[2], b2 = cur[3], c2 = cur[4], thr = cur[5];
+        const float dx = gx_ - fx, dy = gy_ - fy;
+        const float power = a2 * dx * dx + c2 * dy * dy + b2 * dx * dy;
+        const bool cand = idx < last_contrib && power <= 0.f && power >= thr;
+        if (__ballot(cand) == 0ull) continue;
 
-    for (int r = 0; r < rounds; ++r) {
-        const int buf = r & 1;
-        const int top = hi - 1 - r * kBlock;           // list index held by slot 0
-        const int cnt = min(kBlock, top + 1);
-        if (tid < cnt) {
-            pre[0].w = __logf(1.0f / (255.0f * pre[1].w)) - kThrMargin;
+        float v[16];
 #pragma unroll
-            for (int k = 0; k < NV; ++k) stage[buf][tid * NV + k] = pre[k];
-            stage_id[buf][tid] = pre_id;
-        }
-        __syncthreads();
-        if (r + 1 < rounds) gather(r + 1);
-
-        const float4* st = stage[buf];
-        // entries with index >= my_wave_hi contribute to no pixel of this wave
-        const int j0 = max(0, top - (my_wave_hi - 1));
-        for (int j = j0; j < cnt; ++j) {
-            const int idx = top - j;
-            const float4 a = st[j * NV];
-            const float4 b = st[j * NV + 1];
-            const float dx = a.x - fx, dy = a.y - fy;
-            const float power = -0.5f * (b.x * dx * dx + b.z * dy * dy) - b.y * dx * dy;
-            const bool cand = idx < last_contrib && power <= 0.f && power >= a.w;
-            if (__ballot(cand) == 0ull) continue;
-
-            float v[16];
+        for (int k = 0; k < 16; ++k) v[k] = 0.f;
+        bool act = false;
+        if (cand) {
+            const float opac = cur[6];
+            const float G = __expf(power);
+            const float alpha = fminf(0.99f, opac * G);
+            if (alpha >= kAlphaMin) {
+                act = true;
+                const float inv = __frcp_rn(1.0f - alpha);
+                T = T * inv;
+                const float w = alpha * T;
+                float dL_dalpha = 0.f;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] = 0.f;
-            bool act = false;
-            if (cand) {
-                const float G = __expf(power);
-                const float alpha = fminf(0.99f, b.w * G);
-                if (alpha >= kAlphaMin) {
-                    act = true;
-                    const float inv = __frcp_rn(1.0f - alpha);
-                    T = T * inv;
-                    const float w = alpha * T;
-                    float dL_dalpha = 0.f;
-#pragma unroll
-                    for (int f4 = 0; f4 < NF; ++f4) {
-                        const float4 f = st[j * NV + 2 + f4];
-                        const float fc[4] = {f.x, f.y, f.z, f.w};
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int c = 4 * f4 + q;
-                            if (c < C) {
-                                const float diff = fc[q] - R[c];
-                                dL_dalpha += diff * g[c];
-                                R[c] += alpha * diff;
-                                v[c] = w * g[c];
-                            }
-                        }
+                for (int c = 0; c < C; ++c) {
+                    v[c] = w * g[c];
+                    if (c < geom_channels) {
+                        const float diff = rec_j.feat(c) - R[c];
+                        dL_dalpha += diff * g[c];
+                        R[c] += alpha * diff;
                     }
-                    {
-                        const float diff = a.z - Rd;
-                        dL_dalpha += diff * gd;
-                        Rd += alpha * diff;
-                        v[C] = w * gd;
-                    }
-                    {
-                        const float diff = 1.0f - Ra;
-                        dL_dalpha += diff * ga;
-                        Ra += alpha * diff;
-                    }
-                    dL_dalpha *= T;
-                    dL_dalpha -= T_final * inv * bg_dot;
-                    const float dL_dG = b.w * dL_dalpha;
-                    const float gdx = G * dx, gdy = G * dy;
-                    const float dG_ddelx = -gdx * b.x - gdy * b.y;
-                    const float dG_ddely = -gdy * b.z - gdx * b.y;
-                    v[C + 1] = dL_dG * dG_ddelx * halfW;
-                    v[C + 2] = dL_dG * dG_ddely * halfH;
-                    v[C + 3] = -0.5f * gdx * dx * dL_dG;
-                    v[C + 4] = -0.5f * gdx * dy * dL_dG;
-                    v[C + 5] = -0.5f * gdy * dy * dL_dG;
-                    v[C + 6] = G * dL_dalpha;
                 }
+                {
+                    const float diff = cur[7] - Rd;
+                    dL_dalpha += diff * gd;
+                    Rd += alpha * diff;
+                    v[C] = w * gd;
+                }
+                {
+                    const float diff = 1.0f - Ra;
+                    dL_dalpha += diff * ga;
+                    Ra += alpha * diff;
+                }
+                dL_dalpha *= T;
+                dL_dalpha -= T_final * inv * bg_dot;
+                const float dL_dG = opac * dL_dalpha;
+                const float gdx = G * dx, gdy = G * dy;
+                // power = a2*dx^2 + c2*dy^2 + b2*dx*dy with a2 = -A/2, c2 = -C/2, b2 = -B
+                const float dG_ddelx = gdx * (2.f * a2) + gdy * b2;
+                const float dG_ddely = gdy * (2.f * c2) + gdx * b2;
+                v[C + 1] = dL_dG * dG_ddelx * halfW;
+                v[C + 2] = dL_dG * dG_ddely * halfH;
+                v[C + 3] = -0.5f * gdx * dx * dL_dG;
+                v[C + 4] = -0.5f * gdx * dy * dL_dG;
+                v[C + 5] = -0.5f * gdy * dy * dL_dG;
+                v[C + 6] = G * dL_dalpha;
             }
-            if (__ballot(act) == 0ull) continue;
-            const float y = wave_fold16(v);
-            const int slot = lane >> 2;
-            if ((lane & 3) == 0 && slot < C + 7) {
-                const uint32_t gid = stage_id[buf][j];
-                atomicAdd(grad_rec + (size_t)gid * GS + slot, y);
-            }
+        }
+        if (__ballot(act) == 0ull) continue;
+        const float y = wave_fold16(v);
+        const int slot = lane >> 2;
+        if ((lane & 3) == 0 && slot < C + 7) {
+            const uint32_t gid = __float_as_uint(rec_j.feat(C));
+            atomicAdd(grad_rec + (size_t)gid * GS + slot, y);
         }
     }
 }
@@ -225,25 +193,26 @@ __global__ void wave_fold16_test_kernel(const float* __restrict__ in, float* __r
 }
 
 template <int C>
-int launch_c(const OgsRasterBwdArgs& a, const GeomState& gs, const ImageState& is, float* grad_rec, hipStream_t s) {
+int launch_c(const OgsRasterBwdArgs& a, const ImageState& is, float* grad_rec, hipStream_t s) {
     const int gx = (a.W + kTile - 1) / kTile, gy = (a.H + kTile - 1) / kTile;
-    static constexpr const char* const kNames[4] = {"blend_backward_kernel<3>", "blend_backward_kernel<6>", "blend_backward_kernel<9>", "blend_backward_kernel<12>"};
-    OGS_LAUNCH_NAMED(chan_name<C>(kNames), blend_backward_kernel<C>, dim3(gx * gy), dim3(kBlock), 0, s, (const uint2*)is.ranges,
-                       a.point_list, a.W, a.H, gx, (const float4*)gs.rec, a.bg, a.out_alpha,
-                       (const uint32_t*)is.n_contrib, a.dL_dcolor, a.dL_ddepth, a.dL_dalpha, grad_rec);
+    const int geom_channels = (a.geom_channels > 0 && a.geom_channels < C) ? a.geom_channels : C;
+    static constexpr const char* const kNames[4] = {"blend_backward_kernel<3>", "blend_backward_kernel<6>",
+                                                    "blend_backward_kernel<9>", "blend_backward_kernel<12>"};
+    OGS_LAUNCH_NAMED(chan_name<C>(kNames), blend_backward_kernel<C>, dim3(gx * gy), dim3(kBlock), 0, s,
+                     (const uint2*)is.ranges, (const float*)a.sorted_rec, a.W, a.H, gx, geom_channels, a.bg, a.out_alpha,
+                     (const uint32_t*)is.n_contrib, a.dL_dcolor, a.dL_ddepth, a.dL_dalpha, grad_rec);
     OGS_LAUNCH_CHECK(a.debug, s);
     return OGS_OK;
 }
 
 }  // namespace
 
-int launch_blend_backward(const OgsRasterBwdArgs& a, const GeomState& gs, const ImageState& is, float* grad_rec,
-                          hipStream_t s) {
+int launch_blend_backward(const OgsRasterBwdArgs& a, const ImageState& is, float* grad_rec, hipStream_t s) {
     if (a.num_rendered <= 0) return OGS_OK;
     switch (a.C) {
-        case 3: return launch_c<3>(a, gs, is, grad_rec, s);
-        case 6: return launch_c<6>(a, gs, is, grad_rec, s);
-        case 9: return launch_c<9>(a, gs, is, grad_rec, s);
+        case 3: return launch_c<3>(a, is, grad_rec, s);
+        case 6: return launch_c<6>(a, is, grad_rec, s);
+        case 9: return launch_c<9>(a, is, grad_rec, s);
         default: set_error("backward: unsupported channel count C=%d (3, 6 or 9)", a.C); return OGS_ERR_UNSUPPORTED;
     }
 }

@@ -1,14 +1,16 @@
-// Forward front-to-back alpha blend for gfx950.
+// Forward front-to-back alpha blend for gfx950 -- scalar-path design.
 //
-// One 256-thread workgroup per 16x16 tile; each wave64 owns one 8x8 pixel quadrant so that whole-wave
-// rejection of Gaussians that miss the quadrant is frequent.  Per round, 256 sorted entries of the
-// tile list are gathered (id -> 16-byte-aligned record, float4 loads) into a double-buffered LDS
-// stage: one barrier per round, the next round's gather is issued before the current round is
-// consumed so its HBM/L2 latency hides under the blend loop.  The inner loop reads the staged record
-// with wave-uniform (broadcast) ds_read_b128, evaluates the quadratic form, and uses a wave ballot on
-// a conservative log-threshold (power >= ln(1/(255*opacity)) - margin) to skip exp + blend for the
-// whole wave when no lane can reach alpha >= 1/255; surviving lanes run the exact reference test.
-// Early-out: per-wave ballot of `done`, published through LDS, ends the tile when all 4 waves are done.
+// Measured on MI355X (profiles/r01_bench_v1_lds_staged.json): the classic "stage 256 Gaussians in LDS,
+// every pixel thread re-reads them" loop is LDS-ISSUE bound on CDNA4 -- each Gaussian costs a wave two
+// broadcast ds_read_b128 (8 LDS cycles per CU) against ~6 VALU cycles per CU.  The staged data is
+// wave-uniform, so this version moves it to the SCALAR path instead:
+//   1. pack_sorted_kernel: once per pass, gather the per-Gaussian record of every sorted list entry into a
+//      contiguous per-tile stream (coalesced writes; the only random reads of the pass).
+//   2. blend_forward_kernel: one workgroup per 16x16 tile, each wave64 owns an 8x8 quadrant and walks the
+//      tile's stream on its own with s_load_dwordx8/x4 (wave-uniform address -> scalar cache -> SGPR
+//      operands).  No LDS, no barriers; a wave leaves as soon as its 64 pixels are done (ballot).
+// Whole-wave rejection: a ballot on the conservative log-threshold power >= ln(1/(255*opacity)) - margin
+// skips exp + blend when no lane can reach alpha >= 1/255; survivors run the exact reference test.
 // No MFMA: the loop is a per-pixel recurrence, not a contraction.
 #include "ogs_common.h"
 
@@ -19,19 +21,46 @@ namespace {
 constexpr float kAlphaMin = 1.0f / 255.0f;
 constexpr float kThrMargin = 0.01f;
 
+// rec (per Gaussian, preprocess) -> stream record (per sorted list entry):
+//   [0] x  [1] y  [2] -0.5*A  [3] -B  [4] -0.5*C  [5] thr  [6] opacity  [7] depth  [8..8+C) features
+//   [8+C] Gaussian id (bit pattern), rest zero padding to a multiple of 4 floats
+template <int C>
+__global__ __launch_bounds__(kBlock) void pack_sorted_kernel(const uint32_t* __restrict__ point_list, int64_t D,
+                                                             const float4* __restrict__ rec,
+                                                             float4* __restrict__ stream) {
+    constexpr int NV = rec_vec4(C);
+    constexpr int SV = stream_vec4(C);
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= D) return;
+    const uint32_t gid = point_list[i];
+    const float4* src = rec + (size_t)gid * NV;
+    const float4 a = src[0], b = src[1];
+    float f[(SV - 2) * 4];
+#pragma unroll
+    for (int k = 0; k < (SV - 2) * 4; ++k) f[k] = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV - 2; ++v) {
+        const float4 t = src[2 + v];
+        f[4 * v] = t.x; f[4 * v + 1] = t.y; f[4 * v + 2] = t.z; f[4 * v + 3] = t.w;
+    }
+    f[C] = __uint_as_float(gid);
+    float4* dst = stream + (size_t)i * SV;
+    const float thr = __logf(1.0f / (255.0f * b.w)) - kThrMargin;
+    dst[0] = make_float4(a.x, a.y, -0.5f * b.x, -b.y);
+    dst[1] = make_float4(-0.5f * b.z, thr, b.w, a.z);
+#pragma unroll
+    for (int v = 0; v < SV - 2; ++v) dst[2 + v] = make_float4(f[4 * v], f[4 * v + 1], f[4 * v + 2], f[4 * v + 3]);
+}
+
 template <int C>
 __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx,
-    const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ out_color,
-    float* __restrict__ out_depth, float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib) {
-    constexpr int NV = rec_vec4(C);
-    constexpr int NF = NV - 2;
-    __shared__ float4 stage[2][kBlock * NV];
-    __shared__ int wave_done[2][kBlock / kWave];
-
+    const uint2* __restrict__ ranges, const float* __restrict__ stream, int W, int H, int gx,
+    const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ out_depth,
+    float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib) {
+    constexpr int RS = stream_vec4(C) * 4;      // floats per stream record
     const int tile = blockIdx.x;
     const int tx = tile % gx, ty = tile / gx;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int px = tx * kTile + (wave & 1) * 8 + (lane & 7);
     const int py = ty * kTile + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = px < W && py < H;
@@ -39,7 +68,7 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
 
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
-    const int rounds = (n + kBlock - 1) / kBlock;
+    const float* __restrict__ base = stream + (size_t)range.x * RS;
 
     bool done = !inside;
     float T = 1.0f;
@@ -49,67 +78,36 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
     float dacc = 0.f, wacc = 0.f;
     uint32_t last = 0;
 
-    float4 pre[NV];
-    auto gather = [&](int r) {
-        const int i = r * kBlock + tid;
-        if (i < n) {
-            const uint32_t gid = point_list[range.x + i];
-            const float4* src = rec + (size_t)gid * NV;
-#pragma unroll
-            for (int k = 0; k < NV; ++k) pre[k] = src[k];
+    // software pipeline: the 8 geometry dwords of entry j+1 are requested (s_load_dwordx8, wave-uniform
+    // address) before entry j is consumed, so the scalar-cache / L2 latency overlaps the VALU work
+    StreamRec<C> nrec;
+    if (n > 0) nrec.load(base);
+    for (int j = 0; j < n; ++j) {
+        const float* __restrict__ r = base + (size_t)j * RS;      // wave-uniform -> scalar loads
+        const StreamRec<C> rec_j = nrec;
+        const f8 cur = rec_j.g;
+        if (j + 1 < n) nrec.load(r + RS);
+        const float dx = cur[0] - fx, dy = cur[1] - fy;
+        const float power = cur[2] * dx * dx + cur[4] * dy * dy + cur[3] * dx * dy;
+        const bool cand = !done && power <= 0.f && power >= cur[5];
+        if (__ballot(cand) == 0ull) {
+            if ((j & 7) == 7 && __ballot(!done) == 0ull) break;
+            continue;
         }
-    };
-    if (rounds > 0) gather(0);
-
-    for (int r = 0; r < rounds; ++r) {
-        const int buf = r & 1;
-        const int cnt = min(kBlock, n - r * kBlock);
-        if (tid < cnt) {
-            // replace the (blend-irrelevant) radius slot by the conservative log threshold
-            pre[0].w = __logf(1.0f / (255.0f * pre[1].w)) - kThrMargin;
+        if (cand) {
+            const float alpha = fminf(0.99f, cur[6] * __expf(power));
+            if (alpha >= kAlphaMin) {
+                const float test_T = T * (1.0f - alpha);
+                if (test_T < 0.0001f) {
+                    done = true;
+                } else {
+                    const float w = alpha * T;
 #pragma unroll
-            for (int k = 0; k < NV; ++k) stage[buf][tid * NV + k] = pre[k];
-        }
-        const bool wave_all_done = __ballot(!done) == 0ull;
-        if (lane == 0) wave_done[buf][wave] = wave_all_done ? 1 : 0;
-        __syncthreads();
-        if (wave_done[buf][0] & wave_done[buf][1] & wave_done[buf][2] & wave_done[buf][3]) break;
-        if (r + 1 < rounds) gather(r + 1);
-        if (wave_all_done) continue;
-
-        const float4* st = stage[buf];
-        const uint32_t base = (uint32_t)(r * kBlock);
-        for (int j = 0; j < cnt; ++j) {
-            const float4 a = st[j * NV];
-            const float4 b = st[j * NV + 1];
-            const float dx = a.x - fx, dy = a.y - fy;
-            const float power = -0.5f * (b.x * dx * dx + b.z * dy * dy) - b.y * dx * dy;
-            const bool cand = !done && power <= 0.f && power >= a.w;
-            if (__ballot(cand) == 0ull) {
-                if ((j & 31) == 31 && __ballot(!done) == 0ull) break;
-                continue;
-            }
-            if (cand) {
-                const float alpha = fminf(0.99f, b.w * __expf(power));
-                if (alpha >= kAlphaMin) {
-                    const float test_T = T * (1.0f - alpha);
-                    if (test_T < 0.0001f) {
-                        done = true;
-                    } else {
-                        const float w = alpha * T;
-#pragma unroll
-                        for (int v = 0; v < NF; ++v) {
-                            const float4 f = st[j * NV + 2 + v];
-                            if (4 * v + 0 < C) acc[4 * v + 0] += f.x * w;
-                            if (4 * v + 1 < C) acc[4 * v + 1] += f.y * w;
-                            if (4 * v + 2 < C) acc[4 * v + 2] += f.z * w;
-                            if (4 * v + 3 < C) acc[4 * v + 3] += f.w * w;
-                        }
-                        dacc += a.z * w;
-                        wacc += w;
-                        T = test_T;
-                        last = base + (uint32_t)j + 1u;
-                    }
+                    for (int c = 0; c < C; ++c) acc[c] += rec_j.feat(c) * w;
+                    dacc += cur[7] * w;
+                    wacc += w;
+                    T = test_T;
+                    last = (uint32_t)j + 1u;
                 }
             }
         }
@@ -127,24 +125,34 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
 }
 
 template <int C>
-int launch_c(const OgsRasterFwdArgs& a, const GeomState& gs, const ImageState& is, hipStream_t s) {
+int launch_c(const OgsRasterFwdArgs& a, const GeomState& gs, const ImageState& is, int64_t D, hipStream_t s) {
     const int gx = (a.W + kTile - 1) / kTile, gy = (a.H + kTile - 1) / kTile;
-    static constexpr const char* const kNames[4] = {"blend_forward_kernel<3>", "blend_forward_kernel<6>", "blend_forward_kernel<9>", "blend_forward_kernel<12>"};
-    OGS_LAUNCH_NAMED(chan_name<C>(kNames), blend_forward_kernel<C>, dim3(gx * gy), dim3(kBlock), 0, s, (const uint2*)is.ranges,
-                       (const uint32_t*)a.point_list, a.W, a.H, gx, (const float4*)gs.rec, a.bg, a.out_color,
-                       a.out_depth, a.out_alpha, is.n_contrib);
+    if (D > 0) {
+        static constexpr const char* const kPack[4] = {"pack_sorted_kernel<3>", "pack_sorted_kernel<6>",
+                                                       "pack_sorted_kernel<9>", "pack_sorted_kernel<12>"};
+        const int grid = (int)((D + kBlock - 1) / kBlock);
+        OGS_LAUNCH_NAMED(chan_name<C>(kPack), pack_sorted_kernel<C>, dim3(grid), dim3(kBlock), 0, s,
+                         (const uint32_t*)a.point_list, D, (const float4*)gs.rec, (float4*)a.sorted_rec);
+        OGS_LAUNCH_CHECK(a.debug, s);
+    }
+    static constexpr const char* const kNames[4] = {"blend_forward_kernel<3>", "blend_forward_kernel<6>",
+                                                    "blend_forward_kernel<9>", "blend_forward_kernel<12>"};
+    OGS_LAUNCH_NAMED(chan_name<C>(kNames), blend_forward_kernel<C>, dim3(gx * gy), dim3(kBlock), 0, s,
+                     (const uint2*)is.ranges, (const float*)a.sorted_rec, a.W, a.H, gx, a.bg, a.out_color, a.out_depth,
+                     a.out_alpha, is.n_contrib);
     OGS_LAUNCH_CHECK(a.debug, s);
     return OGS_OK;
 }
 
 }  // namespace
 
-int launch_blend_forward(const OgsRasterFwdArgs& a, const GeomState& gs, const ImageState& is, hipStream_t s) {
+int launch_blend_forward(const OgsRasterFwdArgs& a, const GeomState& gs, const ImageState& is, int64_t D,
+                         hipStream_t s) {
     switch (a.C) {
-        case 3: return launch_c<3>(a, gs, is, s);
-        case 6: return launch_c<6>(a, gs, is, s);
-        case 9: return launch_c<9>(a, gs, is, s);
-        case 12: return launch_c<12>(a, gs, is, s);
+        case 3: return launch_c<3>(a, gs, is, D, s);
+        case 6: return launch_c<6>(a, gs, is, D, s);
+        case 9: return launch_c<9>(a, gs, is, D, s);
+        case 12: return launch_c<12>(a, gs, is, D, s);
         default: set_error("unsupported channel count C=%d", a.C); return OGS_ERR_UNSUPPORTED;
     }
 }

@@ -60,15 +60,18 @@ static int validate_fwd(const OgsRasterFwdArgs* a) {
     if (!a) { set_error("args == NULL"); return OGS_ERR_INVALID_ARG; }
     if (a->P < 0 || a->W <= 0 || a->H <= 0) { set_error("bad sizes P=%d W=%d H=%d", a->P, a->W, a->H); return OGS_ERR_INVALID_ARG; }
     if (a->C != 3 && a->C != 6 && a->C != 9 && a->C != 12) { set_error("C=%d unsupported (3, 6, 9, 12)", a->C); return OGS_ERR_UNSUPPORTED; }
-    if ((a->shs != nullptr) == (a->colors_precomp != nullptr)) {
-        set_error("provide exactly one of shs / colors_precomp"); return OGS_ERR_INVALID_ARG;
+    if (a->shs == nullptr && a->colors_precomp == nullptr) {
+        set_error("provide shs or colors_precomp"); return OGS_ERR_INVALID_ARG;
+    }
+    if (a->shs != nullptr && (a->colors_precomp != nullptr) != (a->C > 3)) {
+        set_error("with shs: C == 3 and no colors_precomp, or C > 3 with colors_precomp holding the C-3 extra channels");
+        return OGS_ERR_INVALID_ARG;
     }
     const bool sr = a->scales != nullptr && a->rotations != nullptr;
     if (sr == (a->cov3D_precomp != nullptr) || (a->scales != nullptr) != (a->rotations != nullptr)) {
         set_error("provide exactly one of (scales, rotations) / cov3D_precomp"); return OGS_ERR_INVALID_ARG;
     }
     if (a->shs) {
-        if (a->C != 3) { set_error("SH colours need C == 3"); return OGS_ERR_INVALID_ARG; }
         if (a->sh_degree < 0 || a->sh_degree > 3 || a->sh_coeffs < (a->sh_degree + 1) * (a->sh_degree + 1)) {
             set_error("sh_degree=%d needs >= %d coefficients, got %d", a->sh_degree, (a->sh_degree + 1) * (a->sh_degree + 1), a->sh_coeffs);
             return OGS_ERR_INVALID_ARG;
@@ -134,6 +137,9 @@ size_t ogs_raster_geom_bytes(int32_t P, int32_t C) { return GeomState::bytes(P >
 size_t ogs_raster_geom_tmp_bytes(int32_t P) { return GeomTmp::bytes(P > 0 ? P : 1); }
 size_t ogs_raster_image_bytes(int32_t W, int32_t H) { return ImageState::bytes(W, H); }
 size_t ogs_raster_binning_tmp_bytes(int64_t D, int32_t, int32_t) { return BinTmp::bytes(D > 0 ? D : 1); }
+size_t ogs_raster_sorted_bytes(int64_t D, int32_t C) {
+    return align_up((size_t)(D > 0 ? D : 1) * stream_vec4(C) * sizeof(float4));
+}
 size_t ogs_raster_backward_tmp_bytes(int32_t P) { return align_up((size_t)(P > 0 ? P : 1) * 16 * sizeof(float)); }
 
 int ogs_raster_forward_geometry(const OgsRasterFwdArgs* a, void* stream_, int64_t* num_rendered_host) {
@@ -197,7 +203,8 @@ int ogs_raster_forward_render(const OgsRasterFwdArgs* a, int64_t D, void* stream
     } else {
         OGS_HIP_CHECK(hipMemsetAsync(is.ranges, 0, (size_t)tiles * sizeof(uint2), s));
     }
-    return launch_blend_forward(*a, gs, is, s);
+    if (D > 0 && !a->sorted_rec) { set_error("sorted_rec == NULL with num_rendered=%lld", (long long)D); return OGS_ERR_INVALID_ARG; }
+    return launch_blend_forward(*a, gs, is, D, s);
 }
 
 int ogs_raster_backward(const OgsRasterBwdArgs* a, void* stream_) {
@@ -214,7 +221,8 @@ int ogs_raster_backward(const OgsRasterBwdArgs* a, void* stream_) {
     const ImageState is = ImageState::carve(const_cast<void*>(a->image_buffer), a->W, a->H);
     float* grad_rec = static_cast<float*>(a->bwd_tmp);
     OGS_HIP_CHECK(hipMemsetAsync(grad_rec, 0, (size_t)a->P * grad_stride(a->C) * sizeof(float), s));
-    int rc = launch_blend_backward(*a, gs, is, grad_rec, s);
+    if (a->num_rendered > 0 && !a->sorted_rec) { set_error("backward: sorted_rec == NULL"); return OGS_ERR_INVALID_ARG; }
+    int rc = launch_blend_backward(*a, is, grad_rec, s);
     if (rc != OGS_OK) return rc;
     return launch_preprocess_backward(*a, gs, grad_rec, s);
 }

@@ -84,6 +84,29 @@ struct Carver {
 //   f4[2..] = C blended feature channels, zero padded to a multiple of 4
 __host__ __device__ constexpr int rec_vec4(int C) { return 2 + (C + 3) / 4; }   // float4 per record
 
+// Per sorted-list-entry stream record read by the blend kernels through the scalar path (blend_fwd.hip):
+// 8 geometry floats + C features + Gaussian id, padded to float4.
+__host__ __device__ constexpr int stream_vec4(int C) { return (8 + C + 1 + 3) / 4; }
+
+typedef float f8 __attribute__((ext_vector_type(8)));
+// One stream record as the blend loops hold it: loaded from a WAVE-UNIFORM address, so hipcc emits
+// s_load_dwordx8 / s_load_dwordx4 and the fields live in SGPRs (operands of the per-pixel VALU math).
+template <int C>
+struct StreamRec {
+    static constexpr int NF4 = stream_vec4(C) - 2;
+    f8 g;               // x, y, -A/2, -B, -C/2, thr, opacity, depth
+    float4 f[NF4];      // features, then the Gaussian id bit pattern at slot C
+    __device__ __forceinline__ void load(const float* __restrict__ p) {
+        g = *reinterpret_cast<const f8*>(p);
+#pragma unroll
+        for (int k = 0; k < NF4; ++k) f[k] = *reinterpret_cast<const float4*>(p + 8 + 4 * k);
+    }
+    __device__ __forceinline__ float feat(int c) const {     // c must be a compile-time constant after unrolling
+        const float4 v = f[c >> 2];
+        return (c & 3) == 0 ? v.x : (c & 3) == 1 ? v.y : (c & 3) == 2 ? v.z : v.w;
+    }
+};
+
 // Per-Gaussian gradient record accumulated by the backward blend (64 B = one atomic segment):
 //   [0..C) dL/dfeature, [C] dL/ddepth, [C+1..C+2] dL/dmean2D (NDC scaled), [C+3..C+5] dL/dconic(A,B,C),
 //   [C+6] dL/dopacity ; C <= 9 fits 16 floats, C == 12 uses 32.
@@ -199,9 +222,9 @@ int launch_duplicate(const OgsRasterFwdArgs& a, const GeomState& gs, const GeomT
                      uint32_t* vals, hipStream_t s);
 int launch_tile_ranges(const uint32_t* tile_keys_sorted, int64_t D, uint2* ranges, int tiles, hipStream_t s,
                        int debug);
-int launch_blend_forward(const OgsRasterFwdArgs& a, const GeomState& gs, const ImageState& is, hipStream_t s);
-int launch_blend_backward(const OgsRasterBwdArgs& a, const GeomState& gs, const ImageState& is, float* grad_rec,
-                          hipStream_t s);
+int launch_blend_forward(const OgsRasterFwdArgs& a, const GeomState& gs, const ImageState& is, int64_t D,
+                         hipStream_t s);
+int launch_blend_backward(const OgsRasterBwdArgs& a, const ImageState& is, float* grad_rec, hipStream_t s);
 int launch_preprocess_backward(const OgsRasterBwdArgs& a, const GeomState& gs, const float* grad_rec,
                                hipStream_t s);
 int launch_wave_fold16_test(const float* in, float* out, hipStream_t s);

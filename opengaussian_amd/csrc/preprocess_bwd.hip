@@ -53,9 +53,11 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
         dL_dmeans2D[3 * idx + 2] = 0.f;
     }
     if (dL_dopacity) dL_dopacity[idx] = gr[C + 6];
+    const int coff = shs != nullptr ? 3 : 0;       // fused pass: channels 0..2 belong to SH
     if (dL_dcolors) {
 #pragma unroll
-        for (int c = 0; c < C; ++c) dL_dcolors[(size_t)idx * C + c] = gr[c];
+        for (int c = 0; c < C; ++c)
+            if (c >= coff) dL_dcolors[(size_t)idx * (C - coff) + (c - coff)] = gr[c];
     }
 
     float dmean[3] = {0.f, 0.f, 0.f};
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
 
         // ---- colour -> SH, view direction -> mean ---------------------------------------------------------
         if (shs != nullptr && dL_dsh != nullptr) {
-            if constexpr (C == 3) {
+            {
                 const uint32_t cl = clamped_in[idx];
                 const float dRGB[3] = {(cl & 1u) ? 0.f : gr[0], (cl & 2u) ? 0.f : gr[1], (cl & 4u) ? 0.f : gr[2]};
                 const float* sh = shs + (size_t)idx * sh_coeffs * 3;

@@ -208,16 +208,18 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(
 
     // 9. colour (the reference computes it only for surviving Gaussians; values of culled ones are
     //    never read, so skipping the SH read for them saves bandwidth)
+    //    Fused pass: SH fills channels 0..2 and colors_precomp [P, C-3] the rest.
+    const int coff = shs != nullptr ? 3 : 0;
     if (colors_precomp != nullptr) {
 #pragma unroll
-        for (int c = 0; c < C; ++c) feat[c] = colors_precomp[(size_t)idx * C + c];
-    } else if (ok) {
-        if constexpr (C == 3) {
-            float rgb[3];
-            float cp[3] = {campos[0], campos[1], campos[2]};
-            sh_to_rgb(idx, sh_degree, sh_coeffs, shs, x, y, z, cp, rgb, clamped);
-            feat[0] = rgb[0]; feat[1] = rgb[1]; feat[2] = rgb[2];
-        }
+        for (int c = 0; c < C; ++c)
+            if (c >= coff) feat[c] = colors_precomp[(size_t)idx * (C - coff) + (c - coff)];
+    }
+    if (shs != nullptr && ok) {
+        float rgb[3];
+        float cp[3] = {campos[0], campos[1], campos[2]};
+        sh_to_rgb(idx, sh_degree, sh_coeffs, shs, x, y, z, cp, rgb, clamped);
+        feat[0] = rgb[0]; feat[1] = rgb[1]; feat[2] = rgb[2];
     }
 
     if (!ok) { pxl = 0.f; pyl = 0.f; cA = cB = cC = 0.f; depth = 0.f; }

@@ -60,8 +60,9 @@ def _require_gpu(t: torch.Tensor, name: str):
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings: GaussianRasterizationSettings):
+                raster_settings: GaussianRasterizationSettings, geom_channels: int = 0):
         rs = raster_settings
+        ctx.geom_channels = int(geom_channels)
         _require_gpu(means3D, "means3D")
         dev = means3D.device
         lib = _lib.lib()
@@ -77,9 +78,12 @@ class _RasterizeGaussians(torch.autograd.Function):
         scl = _f32c(scales)
         rot = _f32c(rotations)
         cov = _f32c(cov3Ds_precomp)
-        Cn = 3 if cols is None else int(cols.shape[1])
+        if shs is not None and cols is not None:
+            Cn = 3 + int(cols.shape[1])        # fused pass: SH -> channels 0..2, colors_precomp -> the rest
+        else:
+            Cn = 3 if cols is None else int(cols.shape[1])
         if Cn not in SUPPORTED_CHANNELS:
-            raise RuntimeError(f"colors_precomp must have 3, 6, 9 or 12 channels, got {Cn}")
+            raise RuntimeError(f"the blended channel count must be 3, 6, 9 or 12, got {Cn}")
         bg = _f32c(rs.bg.to(dev))
         if bg is None or bg.numel() != Cn:
             if bg is not None and bg.numel() == 3 and Cn > 3:      # facade bg is 3-wide: pad with zeros
@@ -125,12 +129,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         D = int(n.value)
         point_list = torch.empty(max(D, 1), dtype=torch.int32, device=dev)
         bin_tmp = u8(lib.ogs_raster_binning_tmp_bytes(D, W, H))
-        a.point_list, a.binning_tmp = ptr(point_list), ptr(bin_tmp)
+        sorted_rec = u8(lib.ogs_raster_sorted_bytes(D, Cn))
+        a.point_list, a.binning_tmp, a.sorted_rec = ptr(point_list), ptr(bin_tmp), ptr(sorted_rec)
         check(lib.ogs_raster_forward_render(C.byref(a), D, stream), "ogs_raster_forward_render")
 
         ctx.num_rendered = D
         ctx.save_for_backward(m3, shs, cols, opac, scl, rot, cov, bg, view, proj, campos, radii, alpha, geom, image,
-                              point_list)
+                              point_list, sorted_rec)
         ctx.mark_non_differentiable(radii)
         return color, radii, depth, alpha
 
@@ -139,9 +144,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         P, Cn = ctx.P, ctx.Cn
         if P == 0:
-            return (None,) * 9
+            return (None,) * 10
         (m3, shs, cols, opac, scl, rot, cov, bg, view, proj, campos, radii, alpha, geom, image,
-         point_list) = ctx.saved_tensors
+         point_list, sorted_rec) = ctx.saved_tensors
         dev = m3.device
         lib = _lib.lib()
         H, W = int(rs.image_height), int(rs.image_width)
@@ -151,7 +156,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         g_m3 = z(P, 3) if need[0] else None
         g_m2 = z(P, 3) if need[1] else None
         g_sh = z(*shs.shape) if (need[2] and shs is not None) else None
-        g_col = z(P, Cn) if (need[3] and cols is not None) else None
+        g_col = z(*cols.shape) if (need[3] and cols is not None) else None
         g_op = z(P, 1) if need[4] else None
         g_scl = z(P, 3) if (need[5] and scl is not None) else None
         g_rot = z(P, 4) if (need[6] and rot is not None) else None
@@ -171,6 +176,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         b.tanfovx, b.tanfovy, b.scale_modifier = float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier)
         b.debug = int(bool(rs.debug))
         b.num_rendered = int(ctx.num_rendered)
+        b.geom_channels = int(ctx.geom_channels)
+        b.sorted_rec = ptr(sorted_rec)
         b.bg, b.means3D, b.colors_precomp, b.shs, b.opacities = ptr(bg), ptr(m3), ptr(cols), ptr(shs), ptr(opac)
         b.scales, b.rotations, b.cov3D_precomp = ptr(scl), ptr(rot), ptr(cov)
         b.viewmatrix, b.projmatrix, b.campos = ptr(view), ptr(proj), ptr(campos)
@@ -180,13 +187,30 @@ class _RasterizeGaussians(torch.autograd.Function):
         b.dL_dmeans2D, b.dL_dcolors, b.dL_dopacity, b.dL_dmeans3D = ptr(g_m2), ptr(g_col), ptr(g_op), ptr(g_m3)
         b.dL_dcov3D, b.dL_dsh, b.dL_dscales, b.dL_drotations = ptr(g_cov), ptr(g_sh), ptr(g_scl), ptr(g_rot)
         check(lib.ogs_raster_backward(C.byref(b), _stream()), "ogs_raster_backward")
-        return g_m3, g_m2, g_sh, g_col, g_op, g_scl, g_rot, g_cov, None
+        return g_m3, g_m2, g_sh, g_col, g_op, g_scl, g_rot, g_cov, None, None
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings)
+                                     cov3Ds_precomp, raster_settings, 0)
+
+
+def rasterize_fused(means3D, means2D, opacities, shs, extra_feats, raster_settings, scales=None, rotations=None,
+                    cov3D_precomp=None, detach_extra_from_geometry=True):
+    """ONE pass for what the reference renders in several (gaussian_renderer/__init__.py:104-163): RGB from SH in
+    channels 0..2 plus `extra_feats` [P, 3|6|9] (e.g. the 6-D ins_feat) in the following channels -- one
+    preprocess / sort / blend for all of them.  Returns (color [3+E,H,W], radii, depth, alpha).
+
+    detach_extra_from_geometry=True reproduces the stage-1/2 training graph (train.py:431-436): the loss on the
+    extra channels reaches only `extra_feats`; geometry, opacity and means2D receive gradient from the RGB /
+    depth / alpha outputs alone -- bit-for-bit what two separate reference passes (RGB with all gradients, feature
+    pass with everything else detached) would accumulate."""
+    empty = torch.Tensor([])
+    return _RasterizeGaussians.apply(means3D, means2D, shs, extra_feats, opacities,
+                                     empty if scales is None else scales, empty if rotations is None else rotations,
+                                     empty if cov3D_precomp is None else cov3D_precomp, raster_settings,
+                                     3 if detach_extra_from_geometry else 0)
 
 
 class GaussianRasterizer(nn.Module):

@@ -71,7 +71,7 @@ def hip_export_binning(color_tensor):
     fn = color_tensor.grad_fn
     ctx = fn
     (m3, shs, cols, opac, scl, rot, cov, bg, view, proj, campos, radii, alpha, geom, image,
-     point_list) = ctx.saved_tensors
+     point_list, sorted_rec) = ctx.saved_tensors
     rs = ctx.raster_settings
     D = ctx.num_rendered
     W, H = int(rs.image_width), int(rs.image_height)

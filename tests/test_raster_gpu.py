@@ -141,6 +141,70 @@ def test_backward_parity_6ch(gpu_device):
         assert e < GRAD_TOL, f"{k}: relative error {e} (all: {errs})"
 
 
+def test_fused_pass_equals_separate_passes(gpu_device):
+    """rasterize_fused (RGB via SH + 6-D ins_feat in ONE pass, feature loss detached from geometry) must give
+    what the reference's separate passes give: pass A = RGB with all gradients, pass B = 6 feature channels
+    with everything but the features detached (gaussian_renderer/__init__.py:104-151, train.py:431-436)."""
+    from opengaussian_amd.rasterizer import GaussianRasterizer, rasterize_fused
+    W, H, f = 160, 96, 120.0
+    sc, cam = helpers.tiny_scene(2500, W, H, f, seed=12)
+    dev = gpu_device
+    rs = helpers.settings_for(cam, (0.0, 0.0, 0.0), 3, dev)
+    g = torch.Generator().manual_seed(5)
+    gC, gA, gF = (torch.randn(3, H, W, generator=g).to(dev), torch.randn(1, H, W, generator=g).to(dev),
+                  torch.randn(6, H, W, generator=g).to(dev))
+
+    def leaves():
+        return {k: getattr(sc, k).clone().to(dev).requires_grad_(True)
+                for k in ("means3D", "scales", "rotations", "opacities", "shs", "ins_feat")}
+
+    # separate passes
+    a = leaves()
+    m2 = torch.zeros(2500, 3, device=dev, requires_grad=True)
+    rast = GaussianRasterizer(rs)
+    cA, rA, dA, aA = rast(means3D=a["means3D"], means2D=m2, opacities=a["opacities"], shs=a["shs"], scales=a["scales"],
+                          rotations=a["rotations"])
+    m2b = torch.zeros(2500, 3, device=dev, requires_grad=True)
+    cB, _, _, _ = rast(means3D=a["means3D"].detach(), means2D=m2b, opacities=a["opacities"].detach(),
+                       colors_precomp=a["ins_feat"], scales=a["scales"].detach(), rotations=a["rotations"].detach())
+    torch.autograd.backward([cA, aA, cB], [gC, gA, gF])
+    # fused pass
+    b = leaves()
+    m2f = torch.zeros(2500, 3, device=dev, requires_grad=True)
+    cF, rF, dF, aF = rasterize_fused(b["means3D"], m2f, b["opacities"], b["shs"], b["ins_feat"], rs, scales=b["scales"],
+                                     rotations=b["rotations"])
+    torch.autograd.backward([cF, aF], [torch.cat([gC, gF]), gA])
+    assert torch.equal(rA, rF)
+    torch.testing.assert_close(cF[:3], cA, atol=1e-6, rtol=0)
+    torch.testing.assert_close(cF[3:], cB, atol=1e-6, rtol=0)
+    torch.testing.assert_close(aF, aA, atol=1e-6, rtol=0)
+    for k in ("means3D", "scales", "rotations", "opacities", "shs", "ins_feat"):
+        ga, gb = a[k].grad, b[k].grad
+        scale = float(ga.abs().max()) + 1e-12
+        assert float((ga - gb).abs().max()) / scale < 1e-4, k      # float atomics reorder sums
+    scale = float(m2.grad.abs().max())
+    assert float((m2.grad - m2f.grad).abs().max()) / scale < 1e-4
+
+
+def test_noncontiguous_inputs(gpu_device):
+    """render() feeds sliced / boolean-indexed views (gaussian_renderer/__init__.py:133,204-212)."""
+    from opengaussian_amd.rasterizer import GaussianRasterizer
+    W, H, f = 96, 64, 80.0
+    sc, cam = helpers.tiny_scene(900, W, H, f, seed=13)
+    dev = gpu_device
+    rast = GaussianRasterizer(helpers.settings_for(cam, (0, 0, 0), 3, dev))
+    feat = sc.ins_feat.to(dev)
+    kw = dict(means3D=sc.means3D.to(dev), means2D=torch.zeros(900, 3, device=dev), opacities=sc.opacities.to(dev),
+              scales=sc.scales.to(dev), rotations=sc.rotations.to(dev))
+    c1, *_ = rast(colors_precomp=feat[:, 3:6], **kw)                      # stride-6 view
+    c2, *_ = rast(colors_precomp=feat[:, 3:6].contiguous(), **kw)
+    assert torch.equal(c1, c2)
+    mask = torch.arange(900, device=dev) % 3 != 0
+    c3, r3, *_ = rast(means3D=kw["means3D"][mask], means2D=kw["means2D"][mask], opacities=kw["opacities"][mask],
+                      scales=kw["scales"][mask] * 0.5, rotations=kw["rotations"][mask], colors_precomp=feat[:, :3][mask])
+    assert c3.shape == (3, H, W) and r3.shape == (int(mask.sum()),)
+
+
 def test_empty_and_degenerate(gpu_device):
     from opengaussian_amd.rasterizer import GaussianRasterizer
     sc, cam = helpers.tiny_scene(64, 64, 48, 60.0, seed=9)
