@@ -111,33 +111,32 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     float Rd = 0.f, Ra = 0.f;
     const float halfW = 0.5f * (float)W, halfH = 0.5f * (float)H;
 
-    // software pipeline: request entry idx-1 (s_load_dwordx8, wave-uniform) before consuming entry idx
-    StreamRec<C> nrec;
-    nrec.load(base + (size_t)(hi - 1) * RS);
-    for (int idx = hi - 1; idx >= 0; --idx) {
-        const float* __restrict__ r = base + (size_t)idx * RS;     // wave-uniform -> scalar loads
-        const StreamRec<C> rec_j = nrec;
+    // Same SALU-frugal loop shape as blend_fwd.hip: no break / continue, two ping-pong records (no register
+    // rotation), unconditional prefetch (the stream is padded in front).
+    auto consume = [&](const StreamRec<C>& rec_j, int idx) {
         const f8 cur = rec_j.g;
-        if (idx > 0) nrec.load(r - RS);
-        const float gx_ = cur[0], gy_ = cur[1], a2 = cur[2], b2 = cur[3], c2 = cur[4], thr = cur[5];
-        const float dx = gx_ - fx, dy = gy_ - fy;
+        const float a2 = cur[2], b2 = cur[3], c2 = cur[4];
+        // a pixel whose last contributor lies in front of this entry is parked far away, then ONE compare
+        // |power + h| <= h decides thr <= power <= 0
+        const float fxe = idx < last_contrib ? fx : kFar;
+        const float dx = cur[0] - fxe, dy = cur[1] - fy;
         const float power = a2 * dx * dx + c2 * dy * dy + b2 * dx * dy;
-        const bool cand = idx < last_contrib && power <= 0.f && power >= thr;
-        if (__ballot(cand) == 0ull) continue;
-
-        float v[16];
+        const bool cand = fabsf(power + cur[5]) <= cur[5];
+        if (__ballot(cand) != 0ull) {
+            float v[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = 0.f;
-        bool act = false;
-        if (cand) {
-            const float opac = cur[6];
-            const float G = __expf(power);
-            const float alpha = fminf(0.99f, opac * G);
-            if (alpha >= kAlphaMin) {
-                act = true;
-                const float inv = __frcp_rn(1.0f - alpha);
+            for (int k = 0; k < 16; ++k) v[k] = 0.f;
+            bool act = false;
+            if (cand) {
+                const float opac = cur[6];
+                const float G = __expf(power);
+                const float alpha = fminf(0.99f, opac * G);
+                act = alpha >= kAlphaMin;
+                // rejected lanes run the same arithmetic with alpha = 0 (T, R* unchanged) and a zeroed result
+                const float al = act ? alpha : 0.f;
+                const float inv = __frcp_rn(1.0f - al);
                 T = T * inv;
-                const float w = alpha * T;
+                const float w = al * T;
                 float dL_dalpha = 0.f;
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
@@ -145,22 +144,23 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
                     if (c < geom_channels) {
                         const float diff = rec_j.feat(c) - R[c];
                         dL_dalpha += diff * g[c];
-                        R[c] += alpha * diff;
+                        R[c] += al * diff;
                     }
                 }
                 {
                     const float diff = cur[7] - Rd;
                     dL_dalpha += diff * gd;
-                    Rd += alpha * diff;
+                    Rd += al * diff;
                     v[C] = w * gd;
                 }
                 {
                     const float diff = 1.0f - Ra;
                     dL_dalpha += diff * ga;
-                    Ra += alpha * diff;
+                    Ra += al * diff;
                 }
                 dL_dalpha *= T;
                 dL_dalpha -= T_final * inv * bg_dot;
+                dL_dalpha = act ? dL_dalpha : 0.f;
                 const float dL_dG = opac * dL_dalpha;
                 const float gdx = G * dx, gdy = G * dy;
                 // power = a2*dx^2 + c2*dy^2 + b2*dx*dy with a2 = -A/2, c2 = -C/2, b2 = -B
@@ -173,14 +173,24 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
                 v[C + 5] = -0.5f * gdy * dy * dL_dG;
                 v[C + 6] = G * dL_dalpha;
             }
+            if (__ballot(act) != 0ull) {
+                const float y = wave_fold16(v);
+                const int slot = lane >> 2;
+                if ((lane & 3) == 0 && slot < C + 7) {
+                    const uint32_t gid = __float_as_uint(rec_j.feat(C));
+                    atomicAdd(grad_rec + (size_t)gid * GS + slot, y);
+                }
+            }
         }
-        if (__ballot(act) == 0ull) continue;
-        const float y = wave_fold16(v);
-        const int slot = lane >> 2;
-        if ((lane & 3) == 0 && slot < C + 7) {
-            const uint32_t gid = __float_as_uint(rec_j.feat(C));
-            atomicAdd(grad_rec + (size_t)gid * GS + slot, y);
-        }
+    };
+    StreamRec<C> recA, recB;
+    recA.load(base + (size_t)(hi - 1) * RS);
+    for (int idx = hi - 1; idx >= 0; idx -= 2) {
+        const float* __restrict__ r = base + (size_t)idx * RS;     // wave-uniform -> scalar loads
+        recB.load(r - RS);
+        consume(recA, idx);
+        recA.load(r - 2 * RS);            // may touch the front pad / the previous tile: never consumed
+        if (idx > 0) consume(recB, idx - 1);
     }
 }
 
@@ -199,7 +209,7 @@ int launch_c(const OgsRasterBwdArgs& a, const ImageState& is, float* grad_rec, h
     static constexpr const char* const kNames[4] = {"blend_backward_kernel<3>", "blend_backward_kernel<6>",
                                                     "blend_backward_kernel<9>", "blend_backward_kernel<12>"};
     OGS_LAUNCH_NAMED(chan_name<C>(kNames), blend_backward_kernel<C>, dim3(gx * gy), dim3(kBlock), 0, s,
-                     (const uint2*)is.ranges, (const float*)a.sorted_rec, a.W, a.H, gx, geom_channels, a.bg, a.out_alpha,
+                     (const uint2*)is.ranges, (const float*)stream_base<C>(const_cast<void*>(a.sorted_rec)), a.W, a.H, gx, geom_channels, a.bg, a.out_alpha,
                      (const uint32_t*)is.n_contrib, a.dL_dcolor, a.dL_ddepth, a.dL_dalpha, grad_rec);
     OGS_LAUNCH_CHECK(a.debug, s);
     return OGS_OK;

@@ -22,7 +22,7 @@ constexpr float kAlphaMin = 1.0f / 255.0f;
 constexpr float kThrMargin = 0.01f;
 
 // rec (per Gaussian, preprocess) -> stream record (per sorted list entry):
-//   [0] x  [1] y  [2] -0.5*A  [3] -B  [4] -0.5*C  [5] thr  [6] opacity  [7] depth  [8..8+C) features
+//   [0] x  [1] y  [2] -0.5*A  [3] -B  [4] -0.5*C  [5] h=-thr/2  [6] opacity  [7] depth  [8..8+C) features
 //   [8+C] Gaussian id (bit pattern), rest zero padding to a multiple of 4 floats
 template <int C>
 __global__ __launch_bounds__(kBlock) void pack_sorted_kernel(const uint32_t* __restrict__ point_list, int64_t D,
@@ -45,9 +45,11 @@ __global__ __launch_bounds__(kBlock) void pack_sorted_kernel(const uint32_t* __r
     }
     f[C] = __uint_as_float(gid);
     float4* dst = stream + (size_t)i * SV;
-    const float thr = __logf(1.0f / (255.0f * b.w)) - kThrMargin;
+    // candidate window  thr <= power <= 0  with thr = ln(1/(255*opacity)) - margin, stored as h = -thr/2 so the
+    // kernels test it with one compare |power + h| <= h  (opacity <= 0 gives NaN/-inf: never a candidate)
+    const float h = 0.5f * (__logf(255.0f * b.w) + kThrMargin);
     dst[0] = make_float4(a.x, a.y, -0.5f * b.x, -b.y);
-    dst[1] = make_float4(-0.5f * b.z, thr, b.w, a.z);
+    dst[1] = make_float4(-0.5f * b.z, h, b.w, a.z);
 #pragma unroll
     for (int v = 0; v < SV - 2; ++v) dst[2 + v] = make_float4(f[4 * v], f[4 * v + 1], f[4 * v + 2], f[4 * v + 3]);
 }
@@ -70,7 +72,13 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
     const int n = (int)(range.y - range.x);
     const float* __restrict__ base = stream + (size_t)range.x * RS;
 
-    bool done = !inside;
+    // The loop is written to be SCALAR-ALU frugal (rocprof: the first version issued more SALU than VALU
+    // instructions -- one scalar unit per CU -- because every nested divergent `if` costs exec-mask ops):
+    //   * a finished / outside pixel is "parked" far away (fxe = kFar): its power becomes hugely negative and
+    //     the single candidate compare fails, so no `done` flag enters the control flow;
+    //   * candidate test thr <= power <= 0 is ONE compare: |power + h| <= h with h = -thr/2 from the stream;
+    //   * inside the (single) divergent region everything is selects, not branches.
+    float fxe = inside ? fx : kFar;
     float T = 1.0f;
     float acc[C];
 #pragma unroll
@@ -78,39 +86,44 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
     float dacc = 0.f, wacc = 0.f;
     uint32_t last = 0;
 
-    // software pipeline: the 8 geometry dwords of entry j+1 are requested (s_load_dwordx8, wave-uniform
-    // address) before entry j is consumed, so the scalar-cache / L2 latency overlaps the VALU work
-    StreamRec<C> nrec;
-    if (n > 0) nrec.load(base);
-    for (int j = 0; j < n; ++j) {
-        const float* __restrict__ r = base + (size_t)j * RS;      // wave-uniform -> scalar loads
-        const StreamRec<C> rec_j = nrec;
+    // software pipeline: entry j+1 is requested (s_load_dwordx8 + x4, wave-uniform address) before entry j
+    // is consumed; the stream is padded by one record on both ends so the prefetch needs no bounds test
+    // No break / continue in the loop body (hipcc's structurizer turns them into a scalar state machine):
+    // `all_done` is a wave-uniform flag tested in the loop condition.  Entries are consumed in pairs from two
+    // ping-pong records, so "current = next" costs no register moves.
+    bool all_done = false;
+    auto consume = [&](const StreamRec<C>& rec_j, int j) {
         const f8 cur = rec_j.g;
-        if (j + 1 < n) nrec.load(r + RS);
-        const float dx = cur[0] - fx, dy = cur[1] - fy;
+        const float dx = cur[0] - fxe, dy = cur[1] - fy;
         const float power = cur[2] * dx * dx + cur[4] * dy * dy + cur[3] * dx * dy;
-        const bool cand = !done && power <= 0.f && power >= cur[5];
-        if (__ballot(cand) == 0ull) {
-            if ((j & 7) == 7 && __ballot(!done) == 0ull) break;
-            continue;
-        }
-        if (cand) {
-            const float alpha = fminf(0.99f, cur[6] * __expf(power));
-            if (alpha >= kAlphaMin) {
+        const bool cand = fabsf(power + cur[5]) <= cur[5];
+        if (__ballot(cand) != 0ull) {
+            bool stop = false;
+            if (cand) {
+                float alpha = fminf(0.99f, cur[6] * __expf(power));
+                alpha = alpha >= kAlphaMin ? alpha : 0.f;
                 const float test_T = T * (1.0f - alpha);
-                if (test_T < 0.0001f) {
-                    done = true;
-                } else {
-                    const float w = alpha * T;
+                stop = test_T < 0.0001f;                       // this entry is NOT applied (A.3)
+                const float w = stop ? 0.f : alpha * T;
 #pragma unroll
-                    for (int c = 0; c < C; ++c) acc[c] += rec_j.feat(c) * w;
-                    dacc += cur[7] * w;
-                    wacc += w;
-                    T = test_T;
-                    last = (uint32_t)j + 1u;
-                }
+                for (int c = 0; c < C; ++c) acc[c] += rec_j.feat(c) * w;
+                dacc += cur[7] * w;
+                wacc += w;
+                T = stop ? T : test_T;
+                last = w > 0.f ? (uint32_t)j + 1u : last;
+                fxe = stop ? kFar : fxe;
             }
+            if (__ballot(stop) != 0ull) all_done = __ballot(fxe < kFarTest) == 0ull;   // whole wave finished?
         }
+    };
+    StreamRec<C> recA, recB;
+    recA.load(base);
+    for (int j = 0; j < n && !all_done; j += 2) {
+        const float* __restrict__ r = base + (size_t)j * RS;      // wave-uniform -> scalar loads
+        recB.load(r + RS);
+        consume(recA, j);
+        recA.load(r + 2 * RS);            // may touch the pad record / the next tile: never consumed
+        if (j + 1 < n) consume(recB, j + 1);
     }
 
     if (inside) {
@@ -132,13 +145,13 @@ int launch_c(const OgsRasterFwdArgs& a, const GeomState& gs, const ImageState& i
                                                        "pack_sorted_kernel<9>", "pack_sorted_kernel<12>"};
         const int grid = (int)((D + kBlock - 1) / kBlock);
         OGS_LAUNCH_NAMED(chan_name<C>(kPack), pack_sorted_kernel<C>, dim3(grid), dim3(kBlock), 0, s,
-                         (const uint32_t*)a.point_list, D, (const float4*)gs.rec, (float4*)a.sorted_rec);
+                         (const uint32_t*)a.point_list, D, (const float4*)gs.rec, stream_base<C>(a.sorted_rec));
         OGS_LAUNCH_CHECK(a.debug, s);
     }
     static constexpr const char* const kNames[4] = {"blend_forward_kernel<3>", "blend_forward_kernel<6>",
                                                     "blend_forward_kernel<9>", "blend_forward_kernel<12>"};
     OGS_LAUNCH_NAMED(chan_name<C>(kNames), blend_forward_kernel<C>, dim3(gx * gy), dim3(kBlock), 0, s,
-                     (const uint2*)is.ranges, (const float*)a.sorted_rec, a.W, a.H, gx, a.bg, a.out_color, a.out_depth,
+                     (const uint2*)is.ranges, (const float*)stream_base<C>(a.sorted_rec), a.W, a.H, gx, a.bg, a.out_color, a.out_depth,
                      a.out_alpha, is.n_contrib);
     OGS_LAUNCH_CHECK(a.debug, s);
     return OGS_OK;

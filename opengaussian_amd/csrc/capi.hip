@@ -138,7 +138,7 @@ size_t ogs_raster_geom_tmp_bytes(int32_t P) { return GeomTmp::bytes(P > 0 ? P : 
 size_t ogs_raster_image_bytes(int32_t W, int32_t H) { return ImageState::bytes(W, H); }
 size_t ogs_raster_binning_tmp_bytes(int64_t D, int32_t, int32_t) { return BinTmp::bytes(D > 0 ? D : 1); }
 size_t ogs_raster_sorted_bytes(int64_t D, int32_t C) {
-    return align_up((size_t)(D > 0 ? D : 1) * stream_vec4(C) * sizeof(float4));
+    return align_up((size_t)((D > 0 ? D : 1) + kStreamPad) * stream_vec4(C) * sizeof(float4));
 }
 size_t ogs_raster_backward_tmp_bytes(int32_t P) { return align_up((size_t)(P > 0 ? P : 1) * 16 * sizeof(float)); }
 

@@ -88,6 +88,17 @@ __host__ __device__ constexpr int rec_vec4(int C) { return 2 + (C + 3) / 4; }   
 // 8 geometry floats + C features + Gaussian id, padded to float4.
 __host__ __device__ constexpr int stream_vec4(int C) { return (8 + C + 1 + 3) / 4; }
 
+// The stream buffer carries two unused records in front of entry 0 (one is skipped by stream_base... the
+// backward walk prefetches up to two entries ahead) and two behind entry D-1, so the blend loops can
+// prefetch "the next two records" without a bounds test in either walking direction.
+constexpr int kStreamPad = 4;
+template <int C>
+inline float4* stream_base(void* buf) { return static_cast<float4*>(buf) + 2 * stream_vec4(C); }
+// A pixel that is finished (or outside the image) is parked at this x coordinate: its quadratic form
+// becomes hugely negative, so the single candidate compare of the blend loops rejects it.
+constexpr float kFar = 3.0e18f;
+constexpr float kFarTest = 1.0e18f;
+
 typedef float f8 __attribute__((ext_vector_type(8)));
 // One stream record as the blend loops hold it: loaded from a WAVE-UNIFORM address, so hipcc emits
 // s_load_dwordx8 / s_load_dwordx4 and the fields live in SGPRs (operands of the per-pixel VALU math).

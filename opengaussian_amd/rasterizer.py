@@ -86,8 +86,10 @@ class _RasterizeGaussians(torch.autograd.Function):
             raise RuntimeError(f"the blended channel count must be 3, 6, 9 or 12, got {Cn}")
         bg = _f32c(rs.bg.to(dev))
         if bg is None or bg.numel() != Cn:
-            if bg is not None and bg.numel() == 3 and Cn > 3:      # facade bg is 3-wide: pad with zeros
-                bg = torch.cat([bg, torch.zeros(Cn - 3, device=dev)])
+            if bg is not None and bg.numel() == 3 and Cn > 3:
+                # the facade's bg is 3-wide and the reference applies it to EVERY 3-channel pass (RGB, feat[:, :3],
+                # feat[:, 3:6], gaussian_renderer/__init__.py:55-70,129-151): tile it over the fused channels
+                bg = bg.repeat(Cn // 3)
             else:
                 raise RuntimeError(f"bg must have {Cn} entries")
         view = _f32c(rs.viewmatrix.to(dev))

@@ -1,0 +1,263 @@
+"""``render()`` -- drop-in counterpart of /root/reference/gaussian_renderer/__init__.py:22-373.
+
+Same signature, same flags, same 14-key result dict, same CPU-RNG draws (``torch.rand(1)`` for the rescale
+coin and factor, :121-124) -- but the rasterizer passes are fused wherever the reference re-runs
+preprocess + sort + blend on identical geometry:
+
+  reference (4 passes, :104-163)                    here
+  RGB | feat[:, :3] | feat[:, 3:6] | silhouette  -> ONE 9-channel pass when no rescale is drawn
+                                                    (RGB + 6 feat; alpha is shared), otherwise RGB pass +
+                                                    ONE 6-channel pass whose alpha IS the silhouette
+  per coarse / fine cluster: 2 passes (:203-225,   -> ONE 6-channel pass per cluster
+  :327-345)
+
+The silhouette pass of the reference only keeps alpha (:153), which does not depend on colour, so taking it
+from the feature pass is exact.  Gradients: every blended channel feeds the geometry gradients exactly as in
+separate passes (a sum over channels); whatever the caller detached (train.py:431-436) stays detached.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_fused
+
+C0 = 0.28209479177387814
+C1 = 0.4886025119029199
+C2 = [1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396]
+C3 = [-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658,
+      1.445305721320277, -0.5900435899266435]
+
+
+def eval_sh(deg, sh, dirs):
+    """SH polynomial of utils/sh_utils.py:57-112 (degrees 0-3); sh [..., C, K], dirs [..., 3]."""
+    result = C0 * sh[..., 0]
+    if deg > 0:
+        x, y, z = dirs[..., 0:1], dirs[..., 1:2], dirs[..., 2:3]
+        result = result - C1 * y * sh[..., 1] + C1 * z * sh[..., 2] - C1 * x * sh[..., 3]
+        if deg > 1:
+            xx, yy, zz = x * x, y * y, z * z
+            xy, yz, xz = x * y, y * z, x * z
+            result = (result + C2[0] * xy * sh[..., 4] + C2[1] * yz * sh[..., 5] +
+                      C2[2] * (2.0 * zz - xx - yy) * sh[..., 6] + C2[3] * xz * sh[..., 7] + C2[4] * (xx - yy) * sh[..., 8])
+            if deg > 2:
+                result = (result + C3[0] * y * (3 * xx - yy) * sh[..., 9] + C3[1] * xy * z * sh[..., 10] +
+                          C3[2] * y * (4 * zz - xx - yy) * sh[..., 11] + C3[3] * z * (2 * zz - 3 * xx - 3 * yy) * sh[..., 12] +
+                          C3[4] * x * (4 * zz - xx - yy) * sh[..., 13] + C3[5] * z * (xx - yy) * sh[..., 14] +
+                          C3[6] * x * (xx - 3 * yy) * sh[..., 15])
+    return result
+
+
+def _knn_mean_filter(points: torch.Tensor) -> torch.Tensor:
+    """Outlier mask of the `post_process` branch (:293-309): mean squared distance to the K = sqrt(n) nearest
+    neighbours (self included, as pytorch3d.ops.knn_points(x, x) returns it) below mean + std."""
+    n = points.shape[0]
+    K = max(1, int(n ** 0.5))
+    d2 = torch.cdist(points, points) ** 2
+    knn = torch.topk(d2, K, dim=1, largest=False).values
+    return knn.mean(dim=-1) < knn.mean() + knn.std()
+
+
+def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, iteration,
+           scaling_modifier=1.0, override_color=None, visible_mask=None, mask_num=0,
+           cluster_idx=None, leaf_cluster_idx=None, rescale=True, origin_feat=False,
+           render_feat_map=True, render_color=True, render_cluster=False, better_vis=False,
+           selected_root_id=None, selected_leaf_id=None, pre_mask=None, seg_rgb=False,
+           post_process=False, root_num=64, leaf_num=10):
+    """Render the scene.  Background tensor (bg_color) must be on GPU!"""
+    xyz = pc.get_xyz
+    dev = xyz.device
+    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=dev) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+
+    tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
+    tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
+    raster_settings = GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+        tanfovx=tanfovx, tanfovy=tanfovy, bg=bg_color, scale_modifier=scaling_modifier,
+        viewmatrix=viewpoint_camera.world_view_transform, projmatrix=viewpoint_camera.full_proj_transform,
+        sh_degree=pc.active_sh_degree, campos=viewpoint_camera.camera_center, prefiltered=False, debug=pipe.debug)
+    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+
+    means3D = xyz
+    means2D = screenspace_points
+    opacity = pc.get_opacity
+
+    scales = rotations = cov3D_precomp = None
+    if pipe.compute_cov3D_python:
+        cov3D_precomp = pc.get_covariance(scaling_modifier)
+    else:
+        scales = pc.get_scaling
+        rotations = pc.get_rotation
+
+    shs = colors_precomp = None
+    if override_color is None:
+        if pipe.convert_SHs_python:
+            shs_view = pc.get_features.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
+            dir_pp = pc.get_xyz - viewpoint_camera.camera_center.repeat(pc.get_features.shape[0], 1)
+            dir_pp_normalized = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+            colors_precomp = torch.clamp_min(eval_sh(pc.active_sh_degree, shs_view, dir_pp_normalized) + 0.5, 0.0)
+        else:
+            shs = pc.get_features
+    else:
+        colors_precomp = override_color
+
+    # same CPU RNG draws, in the same order, as the reference (:121-124)
+    prob = torch.rand(1)
+    rescale_factor = torch.tensor(1.0, dtype=torch.float32, device=dev)
+    rescaled = bool(prob > 0.5 and rescale)
+    if rescaled:
+        rescale_factor = torch.rand(1).to(dev)
+
+    rendered_image = radii = rendered_depth = rendered_alpha = None
+    rendered_ins_feat = silhouette = None
+    ins_feat = None
+    if render_feat_map:
+        ins_feat = (pc.get_ins_feat(origin=origin_feat) + 1) / 2
+    can_fuse = (render_color and render_feat_map and not rescaled and ins_feat.shape[-1] in (3, 6, 9))
+    if can_fuse:
+        # RGB + features + silhouette on identical geometry: one bin / sort / blend for everything
+        if shs is not None:
+            out, radii, rendered_depth, rendered_alpha = rasterize_fused(
+                means3D, means2D, opacity, shs, ins_feat, raster_settings, scales=scales * rescale_factor,
+                rotations=rotations, cov3D_precomp=cov3D_precomp, detach_extra_from_geometry=False)
+        else:
+            out, radii, rendered_depth, rendered_alpha = rasterizer(
+                means3D=means3D, means2D=means2D, shs=None, colors_precomp=torch.cat((colors_precomp, ins_feat), dim=1),
+                opacities=opacity, scales=scales * rescale_factor, rotations=rotations, cov3D_precomp=cov3D_precomp)
+        rendered_image, rendered_ins_feat = out[:3], out[3:]
+        silhouette = rendered_alpha
+    else:
+        if render_color:
+            rendered_image, radii, rendered_depth, rendered_alpha = rasterizer(
+                means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
+                scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+        if render_feat_map:
+            # `scales * rescale_factor` with scales=None (compute_cov3D_python) raises, as in the reference (:135)
+            if ins_feat.shape[-1] in (3, 6, 9, 12):
+                rendered_ins_feat, _, _, silhouette = rasterizer(
+                    means3D=means3D, means2D=means2D, shs=None, colors_precomp=ins_feat, opacities=opacity,
+                    scales=scales * rescale_factor, rotations=rotations, cov3D_precomp=cov3D_precomp)
+            else:
+                parts = []
+                for lo in range(0, ins_feat.shape[-1], 3):
+                    part, _, _, silhouette = rasterizer(
+                        means3D=means3D, means2D=means2D, shs=None, colors_precomp=ins_feat[:, lo:lo + 3],
+                        opacities=opacity, scales=scales * rescale_factor, rotations=rotations,
+                        cov3D_precomp=cov3D_precomp)
+                    parts.append(part)
+                rendered_ins_feat = torch.cat(parts, dim=0)
+
+    # ---- [Stage 2.2 preprocessing] coarse cluster feature maps (:168-236) ---------------------------------
+    viewed_pts = radii > 0
+    if cluster_idx is not None:
+        num_cluster = cluster_idx.max() + 1
+        cluster_occur = torch.zeros(num_cluster).to(torch.bool)
+    else:
+        cluster_occur = None
+    if render_cluster and cluster_idx is not None and viewed_pts.sum() != 0:
+        ins_feat = (pc.get_ins_feat(origin=origin_feat) + 1) / 2
+        rendered_clusters = []
+        rendered_cluster_silhouettes = []
+        scale_filter = (scales < 0.5).all(dim=1)
+        for idx in range(num_cluster):
+            if not better_vis and idx != selected_root_id:
+                continue
+            if viewpoint_camera.bClusterOccur is not None and viewpoint_camera.bClusterOccur[idx] == False:  # noqa: E712
+                continue
+            filter_idx = (cluster_idx == idx) & viewed_pts
+            if better_vis:
+                filter_idx = filter_idx & scale_filter
+                if filter_idx.sum() < 100:
+                    continue
+            rendered_cluster, _, _, cluster_silhouette = rasterizer(
+                means3D=means3D[filter_idx], means2D=means2D[filter_idx], shs=None,
+                colors_precomp=ins_feat[filter_idx], opacities=opacity[filter_idx],
+                scales=scales[filter_idx] * rescale_factor, rotations=rotations[filter_idx], cov3D_precomp=cov3D_precomp)
+            if cluster_silhouette.max() > 0.8:
+                cluster_occur[idx] = True
+                rendered_clusters.append(rendered_cluster)
+                rendered_cluster_silhouettes.append(cluster_silhouette)
+        if len(rendered_cluster_silhouettes) != 0:
+            rendered_cluster_silhouettes = torch.vstack(rendered_cluster_silhouettes)
+    else:
+        rendered_clusters, rendered_cluster_silhouettes = None, None
+
+    # ---- [Stage 2.2 & 3] fine cluster feature maps (:239-356) --------------------------------------------------
+    if leaf_cluster_idx is not None and leaf_cluster_idx.numel() > 0:
+        ins_feat = (pc.get_ins_feat(origin=origin_feat) + 1) / 2
+        scale_filter = (scales < 0.1).all(dim=1)
+        rendered_leaf_clusters = []
+        rendered_leaf_cluster_silhouettes = []
+        occured_leaf_id = []
+        if selected_leaf_id is None:
+            if selected_root_id is not None:
+                start_leaf = selected_root_id * leaf_num
+                end_leaf = start_leaf + leaf_num
+            else:
+                start_leaf = 0
+                end_leaf = root_num * leaf_num
+            lerf_range = range(start_leaf, end_leaf)
+        else:
+            lerf_range = selected_leaf_id.tolist()
+        for _, leaf_idx in enumerate(lerf_range):
+            if viewpoint_camera.bClusterOccur is not None and viewpoint_camera.bClusterOccur[selected_root_id] == False:  # noqa: E712
+                continue
+            if selected_leaf_id is None:
+                filter_idx = leaf_cluster_idx == leaf_idx
+            else:
+                filter_idx = (leaf_cluster_idx.unsqueeze(1) == selected_leaf_id).any(dim=1)
+            if pre_mask is not None:
+                filter_idx = filter_idx & pre_mask
+            filter_idx = filter_idx & viewed_pts
+            if better_vis:
+                filter_idx = filter_idx & scale_filter
+                if filter_idx.sum() < 100:
+                    continue
+            if post_process:
+                mask = _knn_mean_filter(means3D[filter_idx])
+                filter_idx[filter_idx != 0] = mask
+            if filter_idx.sum() < 10:
+                continue
+            occured_leaf_id.append(leaf_idx)
+            if seg_rgb:
+                rendered_leaf_cluster, _, _, leaf_cluster_silhouette = rasterizer(
+                    means3D=means3D[filter_idx], means2D=means2D[filter_idx], shs=shs[filter_idx], colors_precomp=None,
+                    opacities=opacity[filter_idx], scales=scales[filter_idx], rotations=rotations[filter_idx],
+                    cov3D_precomp=cov3D_precomp)
+                if ins_feat.shape[-1] > 3:      # the reference renders the same RGB twice and stacks it (:336-346)
+                    rendered_leaf_cluster = torch.cat((rendered_leaf_cluster, rendered_leaf_cluster), dim=0)
+            else:
+                rendered_leaf_cluster, _, _, leaf_cluster_silhouette = rasterizer(
+                    means3D=means3D[filter_idx], means2D=means2D[filter_idx], shs=None,
+                    colors_precomp=ins_feat[filter_idx], opacities=opacity[filter_idx], scales=scales[filter_idx],
+                    rotations=rotations[filter_idx], cov3D_precomp=cov3D_precomp)
+            rendered_leaf_clusters.append(rendered_leaf_cluster)
+            rendered_leaf_cluster_silhouettes.append(leaf_cluster_silhouette)
+            if selected_leaf_id is not None and len(rendered_leaf_clusters) > 0:
+                break
+        if len(rendered_leaf_cluster_silhouettes) != 0:
+            rendered_leaf_cluster_silhouettes = torch.vstack(rendered_leaf_cluster_silhouettes)
+    else:
+        rendered_leaf_clusters = None
+        rendered_leaf_cluster_silhouettes = None
+        occured_leaf_id = None
+
+    return {"render": rendered_image,
+            "alpha": rendered_alpha,
+            "depth": rendered_depth,
+            "silhouette": silhouette,
+            "ins_feat": rendered_ins_feat,
+            "cluster_imgs": rendered_clusters,
+            "cluster_silhouettes": rendered_cluster_silhouettes,
+            "leaf_clusters_imgs": rendered_leaf_clusters,
+            "leaf_cluster_silhouettes": rendered_leaf_cluster_silhouettes,
+            "occured_leaf_id": occured_leaf_id,
+            "cluster_occur": cluster_occur,
+            "viewspace_points": screenspace_points,
+            "visibility_filter": radii > 0,
+            "radii": radii}

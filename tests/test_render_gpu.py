@@ -1,0 +1,135 @@
+"""GPU: opengaussian_amd.renderer.render() (fused passes) reproduces the result dict of the reference's
+render() structure (gaussian_renderer/__init__.py:22-373), re-enacted here pass by pass -- 4 separate
+3-channel rasterizer calls, 2 per cluster -- through the same drop-in GaussianRasterizer."""
+import math
+import types
+
+import pytest
+import torch
+
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+class FakeGaussians:
+    """Only what render() reads from scene/gaussian_model.py:GaussianModel (:122-169)."""
+
+    def __init__(self, sc, dev):
+        self._xyz = sc.means3D.to(dev).requires_grad_(True)
+        self._scaling = sc.scales.to(dev).requires_grad_(True)
+        self._rotation = sc.rotations.to(dev).requires_grad_(True)
+        self._opacity = sc.opacities.to(dev).requires_grad_(True)
+        self._features = sc.shs.to(dev).requires_grad_(True)
+        self._ins_feat = (sc.ins_feat.to(dev) * 2 - 1).requires_grad_(True)
+        self.active_sh_degree = 3
+        self.max_sh_degree = 3
+
+    get_xyz = property(lambda s: s._xyz)
+    get_scaling = property(lambda s: s._scaling)
+    get_rotation = property(lambda s: s._rotation)
+    get_opacity = property(lambda s: s._opacity)
+    get_features = property(lambda s: s._features)
+
+    def get_ins_feat(self, origin=False):
+        return torch.nn.functional.normalize(self._ins_feat, dim=1)
+
+    def leaves(self):
+        return [self._xyz, self._scaling, self._rotation, self._opacity, self._features, self._ins_feat]
+
+
+def reference_structured_render(cam, pc, bg, rescale_factor, cluster_idx=None, selected_root_id=None):
+    """The reference's pass structure (:104-163, :184-232), with the drop-in 3-channel rasterizer."""
+    from opengaussian_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    rs = GaussianRasterizationSettings(
+        image_height=cam.image_height, image_width=cam.image_width, tanfovx=math.tan(cam.FoVx * 0.5),
+        tanfovy=math.tan(cam.FoVy * 0.5), bg=bg, scale_modifier=1.0, viewmatrix=cam.world_view_transform,
+        projmatrix=cam.full_proj_transform, sh_degree=pc.active_sh_degree, campos=cam.camera_center, prefiltered=False,
+        debug=False)
+    rast = GaussianRasterizer(rs)
+    m2 = torch.zeros_like(pc.get_xyz, requires_grad=True)
+    kw = dict(means3D=pc.get_xyz, means2D=m2, opacities=pc.get_opacity, rotations=pc.get_rotation, cov3D_precomp=None)
+    img, radii, depth, alpha = rast(shs=pc.get_features, colors_precomp=None, scales=pc.get_scaling, **kw)
+    feat = (pc.get_ins_feat() + 1) / 2
+    f1, _, _, _ = rast(shs=None, colors_precomp=feat[:, :3], scales=pc.get_scaling * rescale_factor, **kw)
+    f2, _, _, _ = rast(shs=None, colors_precomp=feat[:, 3:6], scales=pc.get_scaling * rescale_factor, **kw)
+    _, _, _, sil = rast(shs=pc.get_features, colors_precomp=None, scales=pc.get_scaling * rescale_factor, **kw)
+    out = {"render": img, "alpha": alpha, "depth": depth, "silhouette": sil, "ins_feat": torch.cat((f1, f2), 0),
+           "radii": radii, "viewspace_points": m2}
+    if cluster_idx is not None:
+        sel = (cluster_idx == selected_root_id) & (radii > 0)
+        c1, _, _, _ = rast(means3D=pc.get_xyz[sel], means2D=m2[sel], shs=None, colors_precomp=feat[:, :3][sel],
+                           opacities=pc.get_opacity[sel], scales=pc.get_scaling[sel] * rescale_factor,
+                           rotations=pc.get_rotation[sel], cov3D_precomp=None)
+        c2, _, _, csil = rast(means3D=pc.get_xyz[sel], means2D=m2[sel], shs=None, colors_precomp=feat[:, 3:][sel],
+                              opacities=pc.get_opacity[sel], scales=pc.get_scaling[sel] * rescale_factor,
+                              rotations=pc.get_rotation[sel], cov3D_precomp=None)
+        out["cluster_img"] = torch.cat((c1, c2), 0)
+        out["cluster_sil"] = csil
+    return out
+
+
+@pytest.mark.parametrize("seed,expect_rescale", [(0, False), (1, True)])
+def test_render_matches_reference_pass_structure(gpu_device, seed, expect_rescale):
+    from opengaussian_amd.renderer import render
+    dev = gpu_device
+    W, H, f = 176, 112, 130.0
+    sc, cam = helpers.tiny_scene(3000, W, H, f, seed=21)
+    cam = cam.to(dev)
+    bg = torch.tensor([0.2, 0.1, 0.3], device=dev)
+    pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=False)
+    cluster_idx = (torch.arange(3000, device=dev) % 4)
+
+    # find out what the reference's RNG draws would be for this seed, then replay them on both sides
+    torch.manual_seed(seed)
+    prob = torch.rand(1)
+    factor = torch.rand(1) if prob > 0.5 else torch.tensor(1.0)
+    assert bool(prob > 0.5) == expect_rescale
+
+    pc_a = FakeGaussians(sc, dev)
+    torch.manual_seed(seed)
+    out = render(cam, pc_a, pipe, bg, iteration=1, cluster_idx=cluster_idx, render_cluster=True, selected_root_id=2)
+    pc_b = FakeGaussians(sc, dev)
+    ref = reference_structured_render(cam, pc_b, bg, factor.to(dev), cluster_idx, 2)
+
+    assert set(out) == {"render", "alpha", "depth", "silhouette", "ins_feat", "cluster_imgs", "cluster_silhouettes",
+                        "leaf_clusters_imgs", "leaf_cluster_silhouettes", "occured_leaf_id", "cluster_occur",
+                        "viewspace_points", "visibility_filter", "radii"}
+    assert torch.equal(out["radii"], ref["radii"]) and torch.equal(out["visibility_filter"], ref["radii"] > 0)
+    for k in ("render", "alpha", "depth", "silhouette", "ins_feat"):
+        assert out[k].shape == ref[k].shape, k
+        torch.testing.assert_close(out[k], ref[k], atol=2e-6, rtol=0, msg=lambda m, k=k: f"{k}: {m}")
+    assert out["ins_feat"].shape == (6, H, W) and out["silhouette"].shape == (1, H, W)
+    assert len(out["cluster_imgs"]) == 1 and bool(out["cluster_occur"][2])
+    torch.testing.assert_close(out["cluster_imgs"][0], ref["cluster_img"], atol=2e-6, rtol=0)
+    torch.testing.assert_close(out["cluster_silhouettes"], ref["cluster_sil"], atol=2e-6, rtol=0)
+
+    # gradients of a loss on render + ins_feat + silhouette agree (float atomics and the 2x3 vs 1x6 channel grouping
+    # reorder fp32 sums: 1e-3 of the largest entry)
+    g = torch.Generator().manual_seed(1)
+    gi, gf, gs = (torch.randn(3, H, W, generator=g).to(dev), torch.randn(6, H, W, generator=g).to(dev),
+                  torch.randn(1, H, W, generator=g).to(dev))
+    ((out["render"] * gi).sum() + (out["ins_feat"] * gf).sum() + (out["silhouette"] * gs).sum()).backward()
+    ((ref["render"] * gi).sum() + (ref["ins_feat"] * gf).sum() + (ref["silhouette"] * gs).sum()).backward()
+    for a, b, name in zip(pc_a.leaves(), pc_b.leaves(), ("xyz", "scaling", "rotation", "opacity", "features", "ins_feat")):
+        scale = float(b.grad.abs().max()) + 1e-12
+        assert float((a.grad - b.grad).abs().max()) / scale < 1e-3, name
+    ga, gb = out["viewspace_points"].grad, ref["viewspace_points"].grad
+    assert float((ga - gb).abs().max()) / float(gb.abs().max()) < 1e-3
+
+
+def test_render_post_process_and_leaf_path(gpu_device):
+    from opengaussian_amd.renderer import render
+    dev = gpu_device
+    W, H, f = 96, 64, 80.0
+    sc, cam = helpers.tiny_scene(1200, W, H, f, seed=22)
+    cam = cam.to(dev)
+    pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=True)
+    pc = FakeGaussians(sc, dev)
+    leaf_idx = torch.arange(1200, device=dev) % 6
+    with torch.no_grad():
+        out = render(cam, pc, pipe, torch.zeros(3, device=dev), iteration=1, rescale=False,
+                     leaf_cluster_idx=leaf_idx, selected_leaf_id=torch.tensor([1, 4], device=dev), post_process=True)
+    assert out["occured_leaf_id"] == [1] and len(out["leaf_clusters_imgs"]) == 1
+    assert out["leaf_clusters_imgs"][0].shape == (6, H, W) and out["leaf_cluster_silhouettes"].shape == (1, H, W)
+    assert out["render"].shape == (3, H, W) and float(out["render"].max()) > 0
