@@ -175,7 +175,7 @@ def main():
     rank, world, local = dp.init_from_env("cuda")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    device = torch.device("cuda", local)
+    device = torch.device("cuda", local % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(device)
     import torch.distributed as dist
 

@@ -27,10 +27,16 @@ def init_from_env(device_type: str = "cuda") -> tuple[int, int, int]:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = "nccl" if device_type == "cuda" else "gloo"
+        # "nccl" is RCCL on ROCm.  OGS_DIST_BACKEND=gloo lets several ranks share one GPU for functional
+        # rehearsals of the N > 1 path on a single-GPU box (never used for measurements).
+        backend = os.environ.get("OGS_DIST_BACKEND", "nccl" if device_type == "cuda" else "gloo")
         if device_type == "cuda":
-            torch.cuda.set_device(local)
-            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            dev = local % max(torch.cuda.device_count(), 1)
+            torch.cuda.set_device(dev)
+            if backend == "nccl":
+                dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, local
