@@ -92,7 +92,9 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     const int last_contrib = inside ? (int)n_contrib[pix] : 0;
     const int hi = __builtin_amdgcn_readfirstlane(wave_max_i32(last_contrib));
     if (hi == 0) return;                                 // wave-uniform; no barriers in this kernel
-    const float* __restrict__ base = stream + (size_t)range.x * RS;
+    // this wave's quadrant stream (blend_fwd.hip::pack_sorted_kernel); n_contrib indexes into it
+    const int n_tile = (int)(range.y - range.x);
+    const float* __restrict__ base = stream + ((size_t)range.x * 4 + (size_t)wave * n_tile) * RS;
 
     const float T_final = inside ? 1.0f - out_alpha[pix] : 0.f;
     float T = T_final;

@@ -1,16 +1,23 @@
-// Forward front-to-back alpha blend for gfx950 -- scalar-path design.
+// Forward front-to-back alpha blend for gfx950 -- scalar-path design over
+// per-quadrant compacted streams.
 //
-// Measured on MI355X (profiles/r01_bench_v1_lds_staged.json): the classic "stage 256 Gaussians in LDS,
-// every pixel thread re-reads them" loop is LDS-ISSUE bound on CDNA4 -- each Gaussian costs a wave two
-// broadcast ds_read_b128 (8 LDS cycles per CU) against ~6 VALU cycles per CU.  The staged data is
-// wave-uniform, so this version moves it to the SCALAR path instead:
-//   1. pack_sorted_kernel: once per pass, gather the per-Gaussian record of every sorted list entry into a
-//      contiguous per-tile stream (coalesced writes; the only random reads of the pass).
-//   2. blend_forward_kernel: one workgroup per 16x16 tile, each wave64 owns an 8x8 quadrant and walks the
-//      tile's stream on its own with s_load_dwordx8/x4 (wave-uniform address -> scalar cache -> SGPR
-//      operands).  No LDS, no barriers; a wave leaves as soon as its 64 pixels are done (ballot).
-// Whole-wave rejection: a ballot on the conservative log-threshold power >= ln(1/(255*opacity)) - margin
-// skips exp + blend when no lane can reach alpha >= 1/255; survivors run the exact reference test.
+// History (profiles/): (v1) the classic "stage 256 Gaussians in LDS, every pixel thread
+// re-reads them" loop; (v2) the staged data is wave-uniform, so it moved to the SCALAR path: a packed
+// per-tile record stream read with s_load into SGPRs, no LDS, no barriers; (v3) SQ counters showed the loop
+// SALU-bound -> branch-free body; (v4, this file) measured on the bench scene only 48 % of the reference's
+// (Gaussian, tile) list entries can reach alpha >= 1/255 on ANY pixel of their tile and only 28 % of the
+// (entry, 8x8 quadrant) pairs -- the reference's tile rect is the square around ceil(3 sigma_max).
+//
+//   1. pack_sorted_kernel: one workgroup per tile walks the tile's sorted list, gathers each Gaussian's
+//      record (the only random reads of the pass), runs an EXACT conservative test per 8x8 quadrant
+//      (maximum of the Gaussian's quadratic form over the quadrant's pixel box vs ln(1/(255*opacity)) - margin)
+//      and appends the record to the stream of every quadrant it can reach.  Depth order inside a quadrant
+//      stream is preserved with a block-wide prefix sum over four 16-bit counters packed in one u64.  The
+//      reference-visible binning state (sorted keys, point list, tile ranges) is untouched and stays bit-exact;
+//      dropped entries are exactly those every lane of the quadrant would have skipped.
+//   2. blend_forward_kernel: one workgroup per tile, each wave64 owns one quadrant and walks ITS stream with
+//      wave-uniform scalar loads (s_load_dwordx8/x4 -> SGPR operands of the per-pixel VALU math).  ~3.6x fewer
+//      loop trips than walking the tile list, nearly all of them doing useful blending.
 // No MFMA: the loop is a per-pixel recurrence, not a contraction.
 #include "ogs_common.h"
 
@@ -21,43 +28,123 @@ namespace {
 constexpr float kAlphaMin = 1.0f / 255.0f;
 constexpr float kThrMargin = 0.01f;
 
-// rec (per Gaussian, preprocess) -> stream record (per sorted list entry):
+// max over the box d in [xlo,xhi] x [ylo,yhi] of  -0.5*(A dx^2 + C dy^2) - B dx dy   (A, C > 0, AC - B^2 > 0)
+__device__ __forceinline__ float max_power_in_box(float A, float B, float Cc, float xlo, float xhi, float ylo,
+                                                  float yhi) {
+    if (xlo <= 0.f && xhi >= 0.f && ylo <= 0.f && yhi >= 0.f) return 0.f;
+    auto q = [&](float dx, float dy) { return -0.5f * (A * dx * dx + Cc * dy * dy) - B * dx * dy; };
+    const float nbA = -B / A, nbC = -B / Cc;
+    // concave form, origin outside the box: the maximum sits on an edge, at the clamped 1-D maximiser
+    float m = q(xlo, fminf(fmaxf(nbC * xlo, ylo), yhi));
+    m = fmaxf(m, q(xhi, fminf(fmaxf(nbC * xhi, ylo), yhi)));
+    m = fmaxf(m, q(fminf(fmaxf(nbA * ylo, xlo), xhi), ylo));
+    m = fmaxf(m, q(fminf(fmaxf(nbA * yhi, xlo), xhi), yhi));
+    return m;
+}
+
+__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d) {
+    const uint32_t lo = __shfl_up((uint32_t)v, d, kWave), hi = __shfl_up((uint32_t)(v >> 32), d, kWave);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// stream record (per kept (entry, quadrant) pair):
 //   [0] x  [1] y  [2] -0.5*A  [3] -B  [4] -0.5*C  [5] h=-thr/2  [6] opacity  [7] depth  [8..8+C) features
 //   [8+C] Gaussian id (bit pattern), rest zero padding to a multiple of 4 floats
 template <int C>
-__global__ __launch_bounds__(kBlock) void pack_sorted_kernel(const uint32_t* __restrict__ point_list, int64_t D,
+__global__ __launch_bounds__(kBlock) void pack_sorted_kernel(const uint2* __restrict__ ranges,
+                                                             const uint32_t* __restrict__ point_list, int gx,
                                                              const float4* __restrict__ rec,
-                                                             float4* __restrict__ stream) {
+                                                             float4* __restrict__ stream,
+                                                             uint32_t* __restrict__ qcount) {
     constexpr int NV = rec_vec4(C);
     constexpr int SV = stream_vec4(C);
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= D) return;
-    const uint32_t gid = point_list[i];
-    const float4* src = rec + (size_t)gid * NV;
-    const float4 a = src[0], b = src[1];
-    float f[(SV - 2) * 4];
+    __shared__ uint64_t wave_tot[kBlock / kWave];
+    const int tile = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint2 range = ranges[tile];
+    const int n = (int)(range.y - range.x);
+    const float X0 = (float)((tile % gx) * kTile), Y0 = (float)((tile / gx) * kTile);
+    uint32_t running[4] = {0u, 0u, 0u, 0u};                // kept entries per quadrant so far (block-uniform)
+
+    for (int base = 0; base < n; base += kBlock) {
+        const int i = base + tid;
+        uint32_t mask = 0;
+        float4 a = make_float4(0, 0, 0, 0), b = a;
+        float f[(SV - 2) * 4];
 #pragma unroll
-    for (int k = 0; k < (SV - 2) * 4; ++k) f[k] = 0.f;
+        for (int k = 0; k < (SV - 2) * 4; ++k) f[k] = 0.f;
+        float h = 0.f;
+        if (i < n) {
+            const uint32_t gid = point_list[range.x + i];
+            const float4* src = rec + (size_t)gid * NV;
+            a = src[0]; b = src[1];
 #pragma unroll
-    for (int v = 0; v < NV - 2; ++v) {
-        const float4 t = src[2 + v];
-        f[4 * v] = t.x; f[4 * v + 1] = t.y; f[4 * v + 2] = t.z; f[4 * v + 3] = t.w;
+            for (int v = 0; v < NV - 2; ++v) {
+                const float4 t = src[2 + v];
+                f[4 * v] = t.x; f[4 * v + 1] = t.y; f[4 * v + 2] = t.z; f[4 * v + 3] = t.w;
+            }
+            f[C] = __uint_as_float(gid);
+            // candidate window thr <= power <= 0, thr = ln(1/(255*opacity)) - margin; stored as h = -thr/2 so the
+            // blend loops test it with ONE compare |power + h| <= h (opacity <= 0: NaN/-inf, never a candidate)
+            h = 0.5f * (__logf(255.0f * b.w) + kThrMargin);
+            const float thr = -2.0f * h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float qx = X0 + (float)((q & 1) * 8), qy = Y0 + (float)((q >> 1) * 8);
+                // d = centre - pixel, pixel in [qx, qx+7] x [qy, qy+7]
+                const float m = max_power_in_box(b.x, b.y, b.z, a.x - qx - 7.f, a.x - qx, a.y - qy - 7.f, a.y - qy);
+                if (m >= thr) mask |= 1u << q;
+            }
+        }
+        // block-wide exclusive prefix of the four per-quadrant keep flags (16-bit lanes of one u64)
+        const uint64_t mine = (uint64_t)(mask & 1u) | ((uint64_t)((mask >> 1) & 1u) << 16) |
+                              ((uint64_t)((mask >> 2) & 1u) << 32) | ((uint64_t)((mask >> 3) & 1u) << 48);
+        uint64_t inc = mine;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const uint64_t t = shfl_up_u64(inc, d);
+            if (lane >= d) inc += t;
+        }
+        if (lane == kWave - 1) wave_tot[wave] = inc;
+        __syncthreads();
+        uint64_t before = 0, total = 0;                    // chunk-local: every 16-bit field <= 256
+#pragma unroll
+        for (int w = 0; w < kBlock / kWave; ++w) {
+            const uint64_t t = wave_tot[w];
+            if (w < wave) before += t;
+            total += t;
+        }
+        const uint64_t pos = before + inc - mine;          // exclusive position inside this chunk, per quadrant
+        if (mask) {
+            const float4 r0 = make_float4(a.x, a.y, -0.5f * b.x, -b.y);
+            const float4 r1 = make_float4(-0.5f * b.z, h, b.w, a.z);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (mask & (1u << q)) {
+                    const uint32_t p = running[q] + ((uint32_t)(pos >> (16 * q)) & 0xFFFFu);
+                    float4* dst = stream + ((size_t)range.x * 4 + (size_t)q * n + p) * SV;
+                    dst[0] = r0;
+                    dst[1] = r1;
+#pragma unroll
+                    for (int v = 0; v < SV - 2; ++v)
+                        dst[2 + v] = make_float4(f[4 * v], f[4 * v + 1], f[4 * v + 2], f[4 * v + 3]);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) running[q] += (uint32_t)(total >> (16 * q)) & 0xFFFFu;
+        __syncthreads();
     }
-    f[C] = __uint_as_float(gid);
-    float4* dst = stream + (size_t)i * SV;
-    // candidate window  thr <= power <= 0  with thr = ln(1/(255*opacity)) - margin, stored as h = -thr/2 so the
-    // kernels test it with one compare |power + h| <= h  (opacity <= 0 gives NaN/-inf: never a candidate)
-    const float h = 0.5f * (__logf(255.0f * b.w) + kThrMargin);
-    dst[0] = make_float4(a.x, a.y, -0.5f * b.x, -b.y);
-    dst[1] = make_float4(-0.5f * b.z, h, b.w, a.z);
+    if (tid == 0) {
 #pragma unroll
-    for (int v = 0; v < SV - 2; ++v) dst[2 + v] = make_float4(f[4 * v], f[4 * v + 1], f[4 * v + 2], f[4 * v + 3]);
+        for (int q = 0; q < 4; ++q) qcount[tile * 4 + q] = running[q];
+    }
 }
 
 template <int C>
 __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
-    const uint2* __restrict__ ranges, const float* __restrict__ stream, int W, int H, int gx,
-    const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ out_depth,
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ qcount, const float* __restrict__ stream, int W,
+    int H, int gx, const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ out_depth,
     float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib) {
     constexpr int RS = stream_vec4(C) * 4;      // floats per stream record
     const int tile = blockIdx.x;
@@ -69,15 +156,19 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
     const float fx = (float)px, fy = (float)py;
 
     const uint2 range = ranges[tile];
-    const int n = (int)(range.y - range.x);
-    const float* __restrict__ base = stream + (size_t)range.x * RS;
+    const int n_tile = (int)(range.y - range.x);
+    const int n = (int)qcount[tile * 4 + wave];                        // this quadrant's kept entries
+    const float* __restrict__ base = stream + ((size_t)range.x * 4 + (size_t)wave * n_tile) * RS;
 
     // The loop is written to be SCALAR-ALU frugal (rocprof: the first version issued more SALU than VALU
     // instructions -- one scalar unit per CU -- because every nested divergent `if` costs exec-mask ops):
     //   * a finished / outside pixel is "parked" far away (fxe = kFar): its power becomes hugely negative and
     //     the single candidate compare fails, so no `done` flag enters the control flow;
     //   * candidate test thr <= power <= 0 is ONE compare: |power + h| <= h with h = -thr/2 from the stream;
-    //   * inside the (single) divergent region everything is selects, not branches.
+    //   * inside the (single) divergent region everything is selects, not branches;
+    //   * no break / continue (hipcc's structurizer turns them into a scalar state machine): `all_done` is a
+    //     wave-uniform flag in the loop condition; entries are consumed in pairs from two ping-pong records,
+    //     so "current = next" costs no register moves.
     float fxe = inside ? fx : kFar;
     float T = 1.0f;
     float acc[C];
@@ -85,13 +176,8 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
     for (int c = 0; c < C; ++c) acc[c] = 0.f;
     float dacc = 0.f, wacc = 0.f;
     uint32_t last = 0;
-
-    // software pipeline: entry j+1 is requested (s_load_dwordx8 + x4, wave-uniform address) before entry j
-    // is consumed; the stream is padded by one record on both ends so the prefetch needs no bounds test
-    // No break / continue in the loop body (hipcc's structurizer turns them into a scalar state machine):
-    // `all_done` is a wave-uniform flag tested in the loop condition.  Entries are consumed in pairs from two
-    // ping-pong records, so "current = next" costs no register moves.
     bool all_done = false;
+
     auto consume = [&](const StreamRec<C>& rec_j, int j) {
         const f8 cur = rec_j.g;
         const float dx = cur[0] - fxe, dy = cur[1] - fy;
@@ -116,13 +202,15 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
             if (__ballot(stop) != 0ull) all_done = __ballot(fxe < kFarTest) == 0ull;   // whole wave finished?
         }
     };
+    // software pipeline over the wave-uniform stream: the stream buffer is padded on both ends and quadrant
+    // regions are contiguous, so prefetching up to two records past the end needs no bounds test
     StreamRec<C> recA, recB;
     recA.load(base);
     for (int j = 0; j < n && !all_done; j += 2) {
-        const float* __restrict__ r = base + (size_t)j * RS;      // wave-uniform -> scalar loads
+        const float* __restrict__ r = base + (size_t)j * RS;
         recB.load(r + RS);
         consume(recA, j);
-        recA.load(r + 2 * RS);            // may touch the pad record / the next tile: never consumed
+        recA.load(r + 2 * RS);
         if (j + 1 < n) consume(recB, j + 1);
     }
 
@@ -133,8 +221,36 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
         for (int c = 0; c < C; ++c) out_color[c * plane + pix] = acc[c] + T * bg[c];
         out_depth[pix] = dacc;
         out_alpha[pix] = wacc;
-        n_contrib[pix] = last;
+        n_contrib[pix] = last;          // index into the QUADRANT stream (+1); see export_n_contrib_kernel
     }
+}
+
+// test/diagnostic export: translate the per-quadrant stream index kept in n_contrib back to the reference's
+// convention, the 1-based position in the tile's full sorted list
+template <int C>
+__global__ __launch_bounds__(kBlock) void export_n_contrib_kernel(const uint2* __restrict__ ranges,
+                                                                  const uint32_t* __restrict__ point_list,
+                                                                  const float* __restrict__ stream, int W, int H, int gx,
+                                                                  const uint32_t* __restrict__ n_contrib,
+                                                                  uint32_t* __restrict__ out) {
+    constexpr int RS = stream_vec4(C) * 4;
+    const int tile = blockIdx.x;
+    const int tx = tile % gx, ty = tile / gx;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int px = tx * kTile + (wave & 1) * 8 + (lane & 7);
+    const int py = ty * kTile + (wave >> 1) * 8 + (lane >> 3);
+    if (px >= W || py >= H) return;
+    const uint2 range = ranges[tile];
+    const int n_tile = (int)(range.y - range.x);
+    const uint32_t last = n_contrib[(size_t)py * W + px];
+    uint32_t res = 0;
+    if (last > 0) {
+        const float* r = stream + ((size_t)range.x * 4 + (size_t)wave * n_tile + (last - 1)) * RS;
+        const uint32_t gid = __float_as_uint(r[8 + C]);
+        for (int i = 0; i < n_tile; ++i)
+            if (point_list[range.x + i] == gid) { res = (uint32_t)i + 1u; break; }
+    }
+    out[(size_t)py * W + px] = res;
 }
 
 template <int C>
@@ -143,17 +259,29 @@ int launch_c(const OgsRasterFwdArgs& a, const GeomState& gs, const ImageState& i
     if (D > 0) {
         static constexpr const char* const kPack[4] = {"pack_sorted_kernel<3>", "pack_sorted_kernel<6>",
                                                        "pack_sorted_kernel<9>", "pack_sorted_kernel<12>"};
-        const int grid = (int)((D + kBlock - 1) / kBlock);
-        OGS_LAUNCH_NAMED(chan_name<C>(kPack), pack_sorted_kernel<C>, dim3(grid), dim3(kBlock), 0, s,
-                         (const uint32_t*)a.point_list, D, (const float4*)gs.rec, stream_base<C>(a.sorted_rec));
+        OGS_LAUNCH_NAMED(chan_name<C>(kPack), pack_sorted_kernel<C>, dim3(gx * gy), dim3(kBlock), 0, s,
+                         (const uint2*)is.ranges, (const uint32_t*)a.point_list, gx, (const float4*)gs.rec,
+                         stream_base<C>(a.sorted_rec), is.qcount);
         OGS_LAUNCH_CHECK(a.debug, s);
+    } else {
+        OGS_HIP_CHECK(hipMemsetAsync(is.qcount, 0, (size_t)gx * gy * 4 * sizeof(uint32_t), s));
     }
     static constexpr const char* const kNames[4] = {"blend_forward_kernel<3>", "blend_forward_kernel<6>",
                                                     "blend_forward_kernel<9>", "blend_forward_kernel<12>"};
     OGS_LAUNCH_NAMED(chan_name<C>(kNames), blend_forward_kernel<C>, dim3(gx * gy), dim3(kBlock), 0, s,
-                     (const uint2*)is.ranges, (const float*)stream_base<C>(a.sorted_rec), a.W, a.H, gx, a.bg, a.out_color, a.out_depth,
-                     a.out_alpha, is.n_contrib);
+                     (const uint2*)is.ranges, (const uint32_t*)is.qcount, (const float*)stream_base<C>(a.sorted_rec), a.W,
+                     a.H, gx, a.bg, a.out_color, a.out_depth, a.out_alpha, is.n_contrib);
     OGS_LAUNCH_CHECK(a.debug, s);
+    return OGS_OK;
+}
+
+template <int C>
+int export_c(const OgsRasterFwdArgs& a, const ImageState& is, uint32_t* out, hipStream_t s) {
+    const int gx = (a.W + kTile - 1) / kTile, gy = (a.H + kTile - 1) / kTile;
+    OGS_LAUNCH(export_n_contrib_kernel<C>, dim3(gx * gy), dim3(kBlock), 0, s, (const uint2*)is.ranges,
+               (const uint32_t*)a.point_list, (const float*)stream_base<C>(a.sorted_rec), a.W, a.H, gx,
+               (const uint32_t*)is.n_contrib, out);
+    OGS_LAUNCH_CHECK(0, s);
     return OGS_OK;
 }
 
@@ -166,6 +294,16 @@ int launch_blend_forward(const OgsRasterFwdArgs& a, const GeomState& gs, const I
         case 6: return launch_c<6>(a, gs, is, D, s);
         case 9: return launch_c<9>(a, gs, is, D, s);
         case 12: return launch_c<12>(a, gs, is, D, s);
+        default: set_error("unsupported channel count C=%d", a.C); return OGS_ERR_UNSUPPORTED;
+    }
+}
+
+int launch_export_n_contrib(const OgsRasterFwdArgs& a, const ImageState& is, uint32_t* out, hipStream_t s) {
+    switch (a.C) {
+        case 3: return export_c<3>(a, is, out, s);
+        case 6: return export_c<6>(a, is, out, s);
+        case 9: return export_c<9>(a, is, out, s);
+        case 12: return export_c<12>(a, is, out, s);
         default: set_error("unsupported channel count C=%d", a.C); return OGS_ERR_UNSUPPORTED;
     }
 }

@@ -138,7 +138,8 @@ size_t ogs_raster_geom_tmp_bytes(int32_t P) { return GeomTmp::bytes(P > 0 ? P : 
 size_t ogs_raster_image_bytes(int32_t W, int32_t H) { return ImageState::bytes(W, H); }
 size_t ogs_raster_binning_tmp_bytes(int64_t D, int32_t, int32_t) { return BinTmp::bytes(D > 0 ? D : 1); }
 size_t ogs_raster_sorted_bytes(int64_t D, int32_t C) {
-    return align_up((size_t)((D > 0 ? D : 1) + kStreamPad) * stream_vec4(C) * sizeof(float4));
+    // every tile owns four quadrant regions of capacity n_tile each (only the kept ~1.1 x D records are touched)
+    return align_up((size_t)(4 * (D > 0 ? D : 1) + kStreamPad) * stream_vec4(C) * sizeof(float4));
 }
 size_t ogs_raster_backward_tmp_bytes(int32_t P) { return align_up((size_t)(P > 0 ? P : 1) * 16 * sizeof(float)); }
 
@@ -254,8 +255,14 @@ int ogs_raster_export_binning(const OgsRasterFwdArgs* a, int64_t D, uint64_t* ke
     }
     if (ranges_out)
         OGS_HIP_CHECK(hipMemcpyAsync(ranges_out, is.ranges, (size_t)gx * gy * sizeof(uint2), hipMemcpyDeviceToDevice, s));
-    if (n_contrib_out)
-        OGS_HIP_CHECK(hipMemcpyAsync(n_contrib_out, is.n_contrib, (size_t)a->W * a->H * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    if (n_contrib_out) {
+        if (D > 0) {
+            int rc = launch_export_n_contrib(*a, is, n_contrib_out, s);
+            if (rc != OGS_OK) return rc;
+        } else {
+            OGS_HIP_CHECK(hipMemsetAsync(n_contrib_out, 0, (size_t)a->W * a->H * sizeof(uint32_t), s));
+        }
+    }
     return OGS_OK;
 }
 

@@ -143,14 +143,16 @@ struct GeomState {      // kept until backward
 };
 
 struct ImageState {     // kept until backward
-    uint2* ranges;          // [tiles]
-    uint32_t* n_contrib;    // [W*H]
+    uint2* ranges;          // [tiles] range of the tile in the sorted list (reference-exact)
+    uint32_t* n_contrib;    // [W*H] last contributor, as 1-based index into the pixel's QUADRANT stream
+    uint32_t* qcount;       // [tiles*4] entries kept in each 8x8 quadrant stream
     static ImageState carve(void* p, int W, int H) {
         Carver c(p);
         ImageState s;
         int tiles = ((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile);
         s.ranges = c.take<uint2>(tiles);
         s.n_contrib = c.take<uint32_t>((size_t)W * H);
+        s.qcount = c.take<uint32_t>((size_t)tiles * 4);
         return s;
     }
     static size_t bytes(int W, int H) {
@@ -158,9 +160,11 @@ struct ImageState {     // kept until backward
         int tiles = ((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile);
         c.take<uint2>(tiles);
         c.take<uint32_t>((size_t)W * H);
+        c.take<uint32_t>((size_t)tiles * 4);
         return c.off;
     }
 };
+int launch_export_n_contrib(const OgsRasterFwdArgs& a, const ImageState& is, uint32_t* out, hipStream_t s);
 
 // radix sort / scan (binning.hip) ---------------------------------------------------------------
 constexpr int kSortItems = 16;                         // keys per thread

@@ -83,6 +83,7 @@ def hip_export_binning(color_tensor):
     a = OgsRasterFwdArgs()
     a.P, a.W, a.H, a.C = ctx.P, W, H, ctx.Cn
     a.geom_buffer, a.image_buffer, a.point_list = ptr(geom), ptr(image), ptr(point_list)
+    a.sorted_rec = ptr(sorted_rec)
     _lib.check(_lib.lib().ogs_raster_export_binning(C.byref(a), D, ptr(keys), ptr(ranges), ptr(ncontrib),
                                                     torch.cuda.current_stream().cuda_stream), "export_binning")
     torch.cuda.synchronize()
