@@ -124,64 +124,62 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
         const float dx = cur[0] - fxe, dy = cur[1] - fy;
         const float power = a2 * dx * dx + c2 * dy * dy + b2 * dx * dy;
         const bool cand = fabsf(power + cur[5]) <= cur[5];
-        if (__ballot(cand) != 0ull) {
+        // All 64 lanes run the same straight-line arithmetic (with the per-quadrant streams nearly every entry
+        // has candidates, so a divergent region would save no issue slots, only cost exec-mask SALU ops and a
+        // 16-register zero fill): a lane that does not contribute gets alpha = 0 and G = 0, which leaves its
+        // T / R* untouched and makes every one of its partial gradients exactly 0.
+        const float opac = cur[6];
+        const float Graw = __expf(power);
+        const float alpha = fminf(0.99f, opac * Graw);
+        const bool act = cand && alpha >= kAlphaMin;
+        if (__ballot(act) != 0ull) {
+            const float al = act ? alpha : 0.f;
+            const float G = act ? Graw : 0.f;
             float v[16];
+            const float inv = __frcp_rn(1.0f - al);
+            T = T * inv;
+            const float w = al * T;
+            float dL_dalpha = 0.f;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] = 0.f;
-            bool act = false;
-            if (cand) {
-                const float opac = cur[6];
-                const float G = __expf(power);
-                const float alpha = fminf(0.99f, opac * G);
-                act = alpha >= kAlphaMin;
-                // rejected lanes run the same arithmetic with alpha = 0 (T, R* unchanged) and a zeroed result
-                const float al = act ? alpha : 0.f;
-                const float inv = __frcp_rn(1.0f - al);
-                T = T * inv;
-                const float w = al * T;
-                float dL_dalpha = 0.f;
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    v[c] = w * g[c];
-                    if (c < geom_channels) {
-                        const float diff = rec_j.feat(c) - R[c];
-                        dL_dalpha += diff * g[c];
-                        R[c] += al * diff;
-                    }
+            for (int c = 0; c < C; ++c) {
+                v[c] = w * g[c];
+                if (c < geom_channels) {
+                    const float diff = rec_j.feat(c) - R[c];
+                    dL_dalpha += diff * g[c];
+                    R[c] += al * diff;
                 }
-                {
-                    const float diff = cur[7] - Rd;
-                    dL_dalpha += diff * gd;
-                    Rd += al * diff;
-                    v[C] = w * gd;
-                }
-                {
-                    const float diff = 1.0f - Ra;
-                    dL_dalpha += diff * ga;
-                    Ra += al * diff;
-                }
-                dL_dalpha *= T;
-                dL_dalpha -= T_final * inv * bg_dot;
-                dL_dalpha = act ? dL_dalpha : 0.f;
-                const float dL_dG = opac * dL_dalpha;
-                const float gdx = G * dx, gdy = G * dy;
-                // power = a2*dx^2 + c2*dy^2 + b2*dx*dy with a2 = -A/2, c2 = -C/2, b2 = -B
-                const float dG_ddelx = gdx * (2.f * a2) + gdy * b2;
-                const float dG_ddely = gdy * (2.f * c2) + gdx * b2;
-                v[C + 1] = dL_dG * dG_ddelx * halfW;
-                v[C + 2] = dL_dG * dG_ddely * halfH;
-                v[C + 3] = -0.5f * gdx * dx * dL_dG;
-                v[C + 4] = -0.5f * gdx * dy * dL_dG;
-                v[C + 5] = -0.5f * gdy * dy * dL_dG;
-                v[C + 6] = G * dL_dalpha;
             }
-            if (__ballot(act) != 0ull) {
-                const float y = wave_fold16(v);
-                const int slot = lane >> 2;
-                if ((lane & 3) == 0 && slot < C + 7) {
-                    const uint32_t gid = __float_as_uint(rec_j.feat(C));
-                    atomicAdd(grad_rec + (size_t)gid * GS + slot, y);
-                }
+            {
+                const float diff = cur[7] - Rd;
+                dL_dalpha += diff * gd;
+                Rd += al * diff;
+                v[C] = w * gd;
+            }
+            {
+                const float diff = 1.0f - Ra;
+                dL_dalpha += diff * ga;
+                Ra += al * diff;
+            }
+            dL_dalpha *= T;
+            dL_dalpha -= T_final * inv * bg_dot;
+            const float dL_dG = opac * dL_dalpha;          // multiplied by G (= 0 for idle lanes) below
+            const float gdx = G * dx, gdy = G * dy;
+            // power = a2*dx^2 + c2*dy^2 + b2*dx*dy with a2 = -A/2, c2 = -C/2, b2 = -B
+            const float dG_ddelx = gdx * (2.f * a2) + gdy * b2;
+            const float dG_ddely = gdy * (2.f * c2) + gdx * b2;
+            v[C + 1] = dL_dG * dG_ddelx * halfW;
+            v[C + 2] = dL_dG * dG_ddely * halfH;
+            v[C + 3] = -0.5f * gdx * dx * dL_dG;
+            v[C + 4] = -0.5f * gdx * dy * dL_dG;
+            v[C + 5] = -0.5f * gdy * dy * dL_dG;
+            v[C + 6] = G * dL_dalpha;
+#pragma unroll
+            for (int k = C + 7; k < 16; ++k) v[k] = 0.f;
+            const float y = wave_fold16(v);
+            const int slot = lane >> 2;
+            if ((lane & 3) == 0 && slot < C + 7) {
+                const uint32_t gid = __float_as_uint(rec_j.feat(C));
+                atomicAdd(grad_rec + (size_t)gid * GS + slot, y);
             }
         }
     };

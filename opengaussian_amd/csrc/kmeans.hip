@@ -1,12 +1,17 @@
 // Lloyd k-means for the OpenGaussian codebooks on gfx950 (C ABI: include/ogs_kmeans.h).
 //
-// Per iteration ONE pass over the features: a workgroup stages 256 rows into LDS with coalesced loads,
-// each thread scores its row against all centres (centres broadcast-read from LDS), takes the first
-// minimum, and adds its row into a per-workgroup LDS accumulator [k][d+1] (last column = count) with
-// ds_add_f32.  Workgroups grid-stride over the points and flush one partial table each; a second tiny
-// kernel sums the partial tables in a fixed order and applies the reference's count/centre update.
-// Algorithmic traffic per iteration: N*4*d bytes read (+ N*8 for the final id write).  No MFMA: with
-// d in {6, 9} and k <= 64 the pass is HBM-bound long before the distance arithmetic matters.
+// Per iteration ONE pass over the features.  A workgroup stages 256 rows into LDS with coalesced loads and
+// each thread scores its row against all centres (centres broadcast-read from LDS, first minimum wins).
+// The reference then forms   one_hot(ids)^T @ feat   (scene/kmeans_quantize.py:84,184-187) -- a real matmul,
+// so the accumulate runs on the matrix cores in EXACT fp32: v_mfma_f32_16x16x4_f32 with
+//     A[i][p] = (id[p] == 16*cb + i)      one-hot, built on the fly from the ids just computed
+//     B[p][j] = feat[p][j]  (j < d),  1 (j == d: the count column),  0 otherwise
+// i.e. every MFMA folds 4 points into a 16-cluster x 16-column accumulator tile held in 4 VGPRs.  The result
+// is a k-ordered fp32 fma chain: deterministic, no atomics (the first version used ds_add_f32 and ran at ~1 %
+// of the HBM roofline).  Workgroups grid-stride over the points and flush one partial table each; a small
+// second kernel sums the tables in fixed order and applies the reference's count/centre bookkeeping.
+// Algorithmic traffic per iteration: N*4*d bytes read (+ N*8 for the final id write).
+// Shapes outside the MFMA tiling (k > 256 or d > 15) use the LDS-accumulator fallback kernel.
 #include "ogs_common.h"
 #include "../../include/ogs_kmeans.h"
 
@@ -15,24 +20,136 @@ namespace ogs {
 namespace {
 
 constexpr int kMaxD = OGS_KMEANS_MAX_DIM;
-constexpr int kMaxBlocks = 1024;
+constexpr int kMaxBlocks = 2048;     // 8 workgroups per CU keep the distance loop's LDS/VALU latency covered
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-// WRITE_IDS: final re-assignment (ids only); ACCUM: Lloyd iteration (partials only)
-template <bool ACCUM, bool WRITE_IDS>
-__global__ __launch_bounds__(kBlock) void kmeans_pass_kernel(const float* __restrict__ feat, int64_t N, int d,
-                                                             const float* __restrict__ centers, int k, int k_active,
-                                                             int64_t* __restrict__ ids_out, int64_t id_offset,
-                                                             float* __restrict__ partials) {
+// argmin over the first k_active centres of sum_j (x_j - c_j)^2, sequential fp32 accumulation, no FMA
+// (this file is built with -ffp-contract=off: same operation order as oracle/kmeans_oracle.py).
+// DT > 0: the feature width is a compile-time constant (6 and 9 are the reference's two codebook levels), so
+// the distance loop is straight-line code; DT == 0: generic width d <= 16.
+template <int DT>
+__device__ __forceinline__ int nearest_centre(const float* __restrict__ rows, int row, int d,
+                                              const float* __restrict__ cs, int k_active) {
+    float best = 3.4e38f;
+    int best_id = 0;
+    if constexpr (DT > 0) {
+        float x[DT];
+#pragma unroll
+        for (int j = 0; j < DT; ++j) x[j] = rows[row * DT + j];
+        for (int c = 0; c < k_active; ++c) {
+            const float* cc = cs + c * DT;
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < DT; ++j) {
+                const float t = x[j] - cc[j];
+                s += t * t;
+            }
+            if (s < best) { best = s; best_id = c; }
+        }
+    } else {
+        float x[kMaxD];
+#pragma unroll
+        for (int j = 0; j < kMaxD; ++j) x[j] = j < d ? rows[row * d + j] : 0.f;
+        for (int c = 0; c < k_active; ++c) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < kMaxD; ++j) {
+                if (j < d) {
+                    const float t = x[j] - cs[c * d + j];
+                    s += t * t;
+                }
+            }
+            if (s < best) { best = s; best_id = c; }
+        }
+    }
+    return best_id;
+}
+
+// ---- MFMA path: CB blocks of 16 clusters (k <= 16*CB), d <= 15 ---------------------------------------------------
+// ACCUM: Lloyd iteration (partials only); otherwise final re-assignment (ids only)
+template <int CB, bool ACCUM, int DT>
+__global__ __launch_bounds__(kBlock) void kmeans_mfma_pass_kernel(const float* __restrict__ feat, int64_t N, int d,
+                                                                  const float* __restrict__ centers, int k,
+                                                                  int k_active, int64_t* __restrict__ ids_out,
+                                                                  int64_t id_offset, float* __restrict__ partials) {
     extern __shared__ float smem[];
-    float* cs = smem;                         // [k*d] centres
-    float* rows = cs + k * d;                 // [256*d] staged rows
-    float* acc = rows + kBlock * d;           // [k*(d+1)] accumulators (ACCUM only)
+    float* cs = smem;                                   // [k*d] centres
+    float* rows = cs + k * d;                           // [256*d] staged rows
+    int* ids_s = reinterpret_cast<int*>(rows + kBlock * d);   // [256] ids of the staged rows (-1: no row)
+    float* wtab = reinterpret_cast<float*>(ids_s + kBlock);   // [4][CB*16][16] per-wave tables (ACCUM, epilogue)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < k * d; i += kBlock) cs[i] = centers[i];
+    floatx4 acc[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) acc[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    const int kq = lane >> 4, j = lane & 15;            // MFMA operand coordinates of this lane
+    const int64_t nblk = (N + kBlock - 1) / kBlock;
+    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const int64_t row0 = blk * kBlock;
+        const int nrows = (int)min((int64_t)kBlock, N - row0);
+        const float* src = feat + row0 * d;
+        for (int i = tid; i < nrows * d; i += kBlock) rows[i] = src[i];
+        __syncthreads();
+        int best_id = -1;
+        if (tid < nrows) {
+            best_id = nearest_centre<DT>(rows, tid, d, cs, k_active);
+            if (!ACCUM) ids_out[row0 + tid] = (int64_t)best_id + id_offset;
+        }
+        if (ACCUM) {
+            ids_s[tid] = best_id;
+            __syncthreads();
+            // this wave folds its 64 points, 4 per MFMA
+#pragma unroll 4
+            for (int g = 0; g < 16; ++g) {
+                const int p = wave * 64 + g * 4 + kq;
+                const int id = ids_s[p];
+                float b = 0.f;
+                if (id >= 0) b = j < d ? rows[p * d + j] : (j == d ? 1.0f : 0.f);
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+                    const float a = (id == cb * 16 + j) ? 1.0f : 0.f;
+                    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[cb], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (ACCUM) {
+        // C/D layout of 16x16 MFMA: lane l, register r holds row (l>>4)*4 + r, column l&15
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                wtab[(wave * CB * 16 + cb * 16 + kq * 4 + r) * 16 + j] = acc[cb][r];
+        __syncthreads();
+        float* out = partials + (size_t)blockIdx.x * k * (d + 1);
+        for (int e = tid; e < k * (d + 1); e += kBlock) {
+            const int c = e / (d + 1), col = e - c * (d + 1);
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < kBlock / kWave; ++w) s += wtab[(w * CB * 16 + c) * 16 + col];   // fixed order
+            out[e] = s;
+        }
+    }
+}
+
+// ---- fallback for shapes outside the MFMA tiling: per-workgroup LDS accumulators ---------------------------------
+template <bool ACCUM>
+__global__ __launch_bounds__(kBlock) void kmeans_lds_pass_kernel(const float* __restrict__ feat, int64_t N, int d,
+                                                                 const float* __restrict__ centers, int k, int k_active,
+                                                                 int64_t* __restrict__ ids_out, int64_t id_offset,
+                                                                 float* __restrict__ partials) {
+    extern __shared__ float smem[];
+    float* cs = smem;
+    float* rows = cs + k * d;
+    float* acc = rows + kBlock * d;           // [k*(d+1)] (ACCUM only)
     const int tid = threadIdx.x;
     for (int i = tid; i < k * d; i += kBlock) cs[i] = centers[i];
     if (ACCUM)
         for (int i = tid; i < k * (d + 1); i += kBlock) acc[i] = 0.f;
     __syncthreads();
-
     const int64_t nblk = (N + kBlock - 1) / kBlock;
     for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
         const int64_t row0 = blk * kBlock;
@@ -41,28 +158,11 @@ __global__ __launch_bounds__(kBlock) void kmeans_pass_kernel(const float* __rest
         for (int i = tid; i < nrows * d; i += kBlock) rows[i] = src[i];
         __syncthreads();
         if (tid < nrows) {
-            float x[kMaxD];
-#pragma unroll
-            for (int j = 0; j < kMaxD; ++j) x[j] = j < d ? rows[tid * d + j] : 0.f;
-            float best = 3.4e38f;
-            int best_id = 0;
-            for (int c = 0; c < k_active; ++c) {
-                float s = 0.f;
-#pragma unroll
-                for (int j = 0; j < kMaxD; ++j) {
-                    if (j < d) {
-                        const float t = x[j] - cs[c * d + j];
-                        s += t * t;
-                    }
-                }
-                if (s < best) { best = s; best_id = c; }
-            }
-            if (WRITE_IDS) ids_out[row0 + tid] = (int64_t)best_id + id_offset;
+            const int best_id = nearest_centre<0>(rows, tid, d, cs, k_active);
+            if (!ACCUM) ids_out[row0 + tid] = (int64_t)best_id + id_offset;
             if (ACCUM) {
                 float* a = acc + best_id * (d + 1);
-#pragma unroll
-                for (int j = 0; j < kMaxD; ++j)
-                    if (j < d) atomicAdd(a + j, x[j]);
+                for (int jj = 0; jj < d; ++jj) atomicAdd(a + jj, rows[tid * d + jj]);
                 atomicAdd(a + d, 1.0f);
             }
         }
@@ -74,31 +174,44 @@ __global__ __launch_bounds__(kBlock) void kmeans_pass_kernel(const float* __rest
     }
 }
 
-// centres = sums / counts with the reference's bookkeeping (kmeans_quantize.py:167,186,209,213-214):
+// Stage 1 of the cross-workgroup reduction: slice s of the partial tables -> slices[s][stride]; every element is
+// summed in block order inside its slice (deterministic).
+constexpr int kSlices = 16;
+__global__ __launch_bounds__(kBlock) void kmeans_reduce_kernel(const float* __restrict__ partials, int nblocks,
+                                                               int stride, float* __restrict__ slices) {
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= stride) return;
+    const int per = (nblocks + kSlices - 1) / kSlices;
+    const int b0 = blockIdx.y * per, b1 = min(nblocks, b0 + per);
+    float s = 0.f;
+    for (int b = b0; b < b1; ++b) s += partials[(size_t)b * stride + e];
+    slices[(size_t)blockIdx.y * stride + e] = s;
+}
+
+// Stage 2: centres = sums / counts with the reference's bookkeeping (kmeans_quantize.py:167,186,209,213-214):
 // counts starts at 1e-6, gains n + 1e-6 per chunk, and is reset to 0 only where it exceeded 0.1.
-__global__ __launch_bounds__(kBlock) void kmeans_finalize_kernel(const float* __restrict__ partials, int nblocks,
-                                                                 int k, int d, float eps_total,
-                                                                 float* __restrict__ counts_state,
-                                                                 float* __restrict__ centers) {
-    const int c = blockIdx.x * kBlock + threadIdx.x;
-    if (c >= k) return;
+__global__ __launch_bounds__(1024) void kmeans_finalize_kernel(const float* __restrict__ slices, int k, int d,
+                                                               float eps_total, float* __restrict__ counts_state,
+                                                               float* __restrict__ centers) {
+    extern __shared__ float tot[];            // [k*(d+1)]
     const int stride = k * (d + 1);
-    float sums[kMaxD];
+    for (int e = threadIdx.x; e < stride; e += blockDim.x) {
+        float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < kMaxD; ++j) sums[j] = 0.f;
-    float n = 0.f;
-    for (int b = 0; b < nblocks; ++b) {
-        const float* p = partials + (size_t)b * stride + c * (d + 1);
-#pragma unroll
-        for (int j = 0; j < kMaxD; ++j)
-            if (j < d) sums[j] += p[j];
-        n += p[d];
+        for (int sl = 0; sl < kSlices; ++sl) s += slices[(size_t)sl * stride + e];
+        tot[e] = s;
     }
-    const float cnt = counts_state[c] + (n + eps_total);
-#pragma unroll
-    for (int j = 0; j < kMaxD; ++j)
-        if (j < d) centers[c * d + j] = sums[j] / cnt;
-    counts_state[c] = cnt > 0.1f ? 0.f : cnt;
+    __syncthreads();
+    for (int e = threadIdx.x; e < k * d; e += blockDim.x) {
+        const int c = e / d, jj = e - c * d;
+        const float cnt = counts_state[c] + (tot[c * (d + 1) + d] + eps_total);
+        centers[e] = tot[c * (d + 1) + jj] / cnt;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < k; c += blockDim.x) {
+        const float cnt = counts_state[c] + (tot[c * (d + 1) + d] + eps_total);
+        counts_state[c] = cnt > 0.1f ? 0.f : cnt;
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void fill_kernel(float* p, int n, float v) {
@@ -130,7 +243,15 @@ int pass_blocks(int64_t N) {
     return (int)(nblk < kMaxBlocks ? (nblk > 0 ? nblk : 1) : kMaxBlocks);
 }
 
-size_t pass_lds(int d, int k, bool accum) {
+int cluster_blocks(int d, int k) {       // 0: MFMA tiling not applicable
+    if (d > 15 || k > 256) return 0;
+    return k <= 16 ? 1 : (k <= 64 ? 4 : 16);
+}
+
+size_t mfma_lds(int d, int k, int CB, bool accum) {
+    return sizeof(float) * ((size_t)k * d + (size_t)kBlock * d + kBlock + (accum ? (size_t)4 * CB * 16 * 16 : 0));
+}
+size_t fallback_lds(int d, int k, bool accum) {
     return sizeof(float) * ((size_t)k * d + (size_t)kBlock * d + (accum ? (size_t)k * (d + 1) : 0));
 }
 
@@ -143,6 +264,47 @@ int allow_lds(K kernel, size_t bytes) {
     return OGS_OK;
 }
 
+template <int CB, bool ACCUM, int DT>
+int launch_mfma_d(int nb, hipStream_t s, const float* feat, int64_t N, int d, const float* centers, int k, int k_active,
+                  int64_t* ids_out, int64_t id_offset, float* partials) {
+    const size_t lds = mfma_lds(d, k, CB, ACCUM);
+    int rc = allow_lds(kmeans_mfma_pass_kernel<CB, ACCUM, DT>, lds);
+    if (rc != OGS_OK) return rc;
+    OGS_LAUNCH_NAMED(ACCUM ? "kmeans_mfma_pass_kernel<accum>" : "kmeans_mfma_pass_kernel<assign>",
+                     (kmeans_mfma_pass_kernel<CB, ACCUM, DT>), dim3(nb), dim3(kBlock), lds, s, feat, N, d, centers, k,
+                     k_active, ids_out, id_offset, partials);
+    OGS_LAUNCH_CHECK(0, s);
+    return OGS_OK;
+}
+
+template <int CB, bool ACCUM>
+int launch_mfma(int nb, hipStream_t s, const float* feat, int64_t N, int d, const float* centers, int k, int k_active,
+                int64_t* ids_out, int64_t id_offset, float* partials) {
+    switch (d) {
+        case 6: return launch_mfma_d<CB, ACCUM, 6>(nb, s, feat, N, d, centers, k, k_active, ids_out, id_offset, partials);
+        case 9: return launch_mfma_d<CB, ACCUM, 9>(nb, s, feat, N, d, centers, k, k_active, ids_out, id_offset, partials);
+        default: return launch_mfma_d<CB, ACCUM, 0>(nb, s, feat, N, d, centers, k, k_active, ids_out, id_offset, partials);
+    }
+}
+
+template <bool ACCUM>
+int launch_pass(int nb, hipStream_t s, const float* feat, int64_t N, int d, const float* centers, int k, int k_active,
+                int64_t* ids_out, int64_t id_offset, float* partials) {
+    switch (cluster_blocks(d, k)) {
+        case 1: return launch_mfma<1, ACCUM>(nb, s, feat, N, d, centers, k, k_active, ids_out, id_offset, partials);
+        case 4: return launch_mfma<4, ACCUM>(nb, s, feat, N, d, centers, k, k_active, ids_out, id_offset, partials);
+        case 16: return launch_mfma<16, ACCUM>(nb, s, feat, N, d, centers, k, k_active, ids_out, id_offset, partials);
+        default: break;
+    }
+    const size_t lds = fallback_lds(d, k, ACCUM);
+    int rc = allow_lds(kmeans_lds_pass_kernel<ACCUM>, lds);
+    if (rc != OGS_OK) return rc;
+    OGS_LAUNCH((kmeans_lds_pass_kernel<ACCUM>), dim3(nb), dim3(kBlock), lds, s, feat, N, d, centers, k, k_active, ids_out,
+               id_offset, partials);
+    OGS_LAUNCH_CHECK(0, s);
+    return OGS_OK;
+}
+
 }  // namespace
 }  // namespace ogs
 
@@ -151,7 +313,8 @@ using namespace ogs;
 extern "C" {
 
 size_t ogs_kmeans_tmp_bytes(int64_t N, int32_t d, int32_t k) {
-    return align_up((size_t)pass_blocks(N) * k * (d + 1) * sizeof(float)) + align_up((size_t)k * sizeof(float));
+    return align_up((size_t)pass_blocks(N) * k * (d + 1) * sizeof(float)) + align_up((size_t)k * sizeof(float)) +
+           align_up((size_t)kSlices * k * (d + 1) * sizeof(float));
 }
 
 int ogs_kmeans_assign(const float* feat, int64_t N, int32_t d, const float* centers, int32_t k, int64_t* ids_out,
@@ -160,13 +323,8 @@ int ogs_kmeans_assign(const float* feat, int64_t N, int32_t d, const float* cent
     if (rc != OGS_OK) return rc;
     if (N == 0) return OGS_OK;
     if (!feat || !centers || !ids_out) { set_error("kmeans_assign: NULL pointer"); return OGS_ERR_INVALID_ARG; }
-    hipStream_t s = static_cast<hipStream_t>(stream_);
-    rc = allow_lds(kmeans_pass_kernel<false, true>, pass_lds(d, k, false));
-    if (rc != OGS_OK) return rc;
-    OGS_LAUNCH((kmeans_pass_kernel<false, true>), dim3(pass_blocks(N)), dim3(kBlock), pass_lds(d, k, false), s, feat,
-                       N, d, centers, k, k, ids_out, id_offset, (float*)nullptr);
-    OGS_LAUNCH_CHECK(0, s);
-    return OGS_OK;
+    return launch_pass<false>(pass_blocks(N), static_cast<hipStream_t>(stream_), feat, N, d, centers, k, k, ids_out,
+                              id_offset, nullptr);
 }
 
 int ogs_kmeans_lloyd(const float* feat, int64_t N, int32_t d, float* centers, int32_t k, int32_t k_active,
@@ -180,26 +338,28 @@ int ogs_kmeans_lloyd(const float* feat, int64_t N, int32_t d, float* centers, in
     if (!centers || !tmp || (N > 0 && (!feat || !ids_out))) { set_error("kmeans_lloyd: NULL pointer"); return OGS_ERR_INVALID_ARG; }
     hipStream_t s = static_cast<hipStream_t>(stream_);
     const int nb = pass_blocks(N);
-    rc = allow_lds(kmeans_pass_kernel<true, false>, pass_lds(d, k, true));
-    if (rc != OGS_OK) return rc;
-    rc = allow_lds(kmeans_pass_kernel<false, true>, pass_lds(d, k, false));
-    if (rc != OGS_OK) return rc;
     float* partials = static_cast<float*>(tmp);
     float* counts = reinterpret_cast<float*>(static_cast<char*>(tmp) + align_up((size_t)nb * k * (d + 1) * sizeof(float)));
+    float* slices = reinterpret_cast<float*>(reinterpret_cast<char*>(counts) + align_up((size_t)k * sizeof(float)));
+    const int stride = k * (d + 1);
     OGS_LAUNCH(fill_kernel, dim3((k + kBlock - 1) / kBlock), dim3(kBlock), 0, s, counts, k, 1e-6f);
     OGS_LAUNCH_CHECK(0, s);
+    const size_t fin_lds = (size_t)k * (d + 1) * sizeof(float);
+    rc = allow_lds(kmeans_finalize_kernel, fin_lds);
+    if (rc != OGS_OK) return rc;
     for (int it = 0; it < iters; ++it) {
-        OGS_LAUNCH((kmeans_pass_kernel<true, false>), dim3(nb), dim3(kBlock), pass_lds(d, k, true), s, feat, N, d,
-                           (const float*)centers, k, k_active, (int64_t*)nullptr, (int64_t)0, partials);
+        rc = launch_pass<true>(nb, s, feat, N, d, centers, k, k_active, nullptr, 0, partials);
+        if (rc != OGS_OK) return rc;
+        OGS_LAUNCH(kmeans_reduce_kernel, dim3((stride + kBlock - 1) / kBlock, kSlices), dim3(kBlock), 0, s,
+                   (const float*)partials, nb, stride, slices);
         OGS_LAUNCH_CHECK(0, s);
-        OGS_LAUNCH(kmeans_finalize_kernel, dim3((k + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
-                           (const float*)partials, nb, k, d, (float)nchunks * 1e-6f, counts, centers);
+        OGS_LAUNCH(kmeans_finalize_kernel, dim3(1), dim3(1024), fin_lds, s, (const float*)slices, k, d,
+                   (float)nchunks * 1e-6f, counts, centers);
         OGS_LAUNCH_CHECK(0, s);
     }
     if (N > 0) {
-        OGS_LAUNCH((kmeans_pass_kernel<false, true>), dim3(nb), dim3(kBlock), pass_lds(d, k, false), s, feat, N, d,
-                           (const float*)centers, k, k_active, ids_out, id_offset, (float*)nullptr);
-        OGS_LAUNCH_CHECK(0, s);
+        rc = launch_pass<false>(nb, s, feat, N, d, centers, k, k_active, ids_out, id_offset, nullptr);
+        if (rc != OGS_OK) return rc;
     }
     return OGS_OK;
 }
