@@ -7,13 +7,17 @@
 
 Workload (BASELINE.json `metric`): synthetic S1M-1080p scene -- 1,000,000 Gaussians,
 1920x1080, seed 0 -- one "step" = one VIEW rendered forward AND backward with everything the metric names:
-  pass A  RGB through SH degree 3 (+depth, alpha), backward to means3D / scales / rotations / opacity / SH /
-          means2D  (stage-0 style, all gradient families),
-  pass B  the 6-D ins_feat map as ONE fused 6-channel pass (the reference needs two 3-channel passes,
-          gaussian_renderer/__init__.py:129-151), backward to ins_feat + means2D (stage-1 style).
+  (A) RGB through SH degree 3 (+depth, alpha), backward to means3D / scales / rotations / opacity / SH /
+      means2D  (stage-0 style, all gradient families),
+  (B) the 6-D ins_feat map (the reference needs two 3-channel passes, gaussian_renderer/__init__.py:129-151),
+      backward to ins_feat only (stage-1 style: geometry detached, train.py:431-436).
+Default: (A) and (B) are rendered by ONE fused 9-channel rasterizer pass (rasterize_fused; the backward kernel
+keeps the feature loss out of the geometry gradients, so the gradients equal those of two separate passes --
+tests/test_raster_gpu.py::test_fused_pass_equals_separate_passes).  --separate-passes runs them as two passes
+(3-channel SH + 6-channel), --rgb-only times (A) alone.
 Inputs are resident in HBM before the timed region.  value = views*W*H / time, summed over all ranks
 (weak scaling: rank r renders its own view of the same replicated scene; for N > 1 the per-Gaussian
-gradients of both passes are SUM-all-reduced over RCCL inside the step, overlapped with pass B).
+gradients are SUM-all-reduced over RCCL inside the step as one flat bucket).
 
 One JSON line on rank 0, with `roofline` (dominant kernel, HIP events on the launch stream, algorithmic
 bytes of SURVEY.md section 8(d)) and `cpu_baseline` (the CPU oracle = pure-PyTorch per-tile alpha blend,
