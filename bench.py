@@ -272,7 +272,10 @@ def main():
         torch.cuda.synchronize()
         log(f"warmup step {i} done (D={info.get('D')})")
     barrier()
-    _lib.prof_enable(True)
+    # Timed region.  HIP events on the launch stream bracket ONLY the blend kernels here (mode 2): an event pair
+    # serialises the queue for ~10 us per launch, and a step issues ~50 launches, so bracketing every kernel
+    # inside the timed region would cost ~0.5 ms/step.  The dominant kernel (roofline) is a blend kernel.
+    _lib.prof_enable(2)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         radii = step()
@@ -281,7 +284,15 @@ def main():
     elapsed = time.perf_counter() - t0
     log(f"timed region done: {elapsed / args.steps * 1e3:.3f} ms/step")
     prof = _lib.prof_collect()
-    _lib.prof_enable(False)
+    # second, untimed pass of the same K steps with every launch bracketed: the per-kernel breakdown
+    _lib.prof_enable(1)
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    prof_all = _lib.prof_collect()
+    _lib.prof_enable(0)
+    for name, v in prof_all.items():
+        prof.setdefault(name, v)
     if world > 1:
         te = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)

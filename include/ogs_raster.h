@@ -94,8 +94,9 @@ typedef struct OgsRasterBwdArgs {
     int32_t debug;
     int32_t num_rendered;
     int32_t geom_channels;       /* 0 or C: every channel feeds the geometry/opacity gradients (reference
-                                    behaviour).  0 < g < C: only channels [0,g) + depth + alpha do; channels
-                                    >= g just receive dL/dfeature (fused RGB + detached ins_feat pass) */
+                                    behaviour).  3 (with C > 3): only channels 0..2 + depth + alpha do; channels
+                                    >= 3 just receive dL/dfeature (fused RGB + detached ins_feat pass).  Other
+                                    values are rejected (the value is a compile-time constant of the kernel). */
     const float* bg;
     const float* means3D;
     const float* colors_precomp;
@@ -160,8 +161,10 @@ int ogs_raster_export_binning(const OgsRasterFwdArgs* args, int64_t num_rendered
                               uint32_t* ranges_out, uint32_t* n_contrib_out, void* stream);
 
 /* Optional per-kernel timing with HIP events on the launch stream (used by bench.py's roofline leg;
- * not part of the reference boundary).  enable(1) starts a fresh recording, collect() writes a JSON
- * object {"kernel": {"calls": n, "total_ms": t}, ...} into buf (host memory). */
+ * not part of the reference boundary).  enable(1) starts a fresh recording of every launch, enable(2) of the
+ * blend kernels only (two events per launch serialise the queue for ~10 us, so a timed region brackets only
+ * the dominant kernels), enable(0) stops; collect() writes a JSON object
+ * {"kernel": {"calls": n, "total_ms": t}, ...} into buf (host memory). */
 int ogs_prof_enable(int on);
 int ogs_prof_collect(char* buf, size_t n);
 

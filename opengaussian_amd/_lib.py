@@ -98,8 +98,9 @@ def check(rc: int, what: str):
         raise OgsError(f"{what} failed (code {rc}): {lib().ogs_last_error().decode()}")
 
 
-def prof_enable(on: bool):
-    check(lib().ogs_prof_enable(1 if on else 0), "ogs_prof_enable")
+def prof_enable(mode):
+    """0/False: off, 1/True: every launch, 2: only the blend kernels (cheap enough for a timed region)."""
+    check(lib().ogs_prof_enable(int(mode)), "ogs_prof_enable")
 
 
 def prof_collect() -> dict:

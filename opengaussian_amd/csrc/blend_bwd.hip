@@ -68,9 +68,11 @@ __device__ __forceinline__ int wave_max_i32(int v) {
     return v;
 }
 
-template <int C>
+// GC = geom_channels as a compile-time constant (C: every channel feeds geometry; 3: fused RGB + detached
+// features): a runtime value turned every per-channel update into v_cndmask selects and kept dead math alive.
+template <int C, int GC>
 __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
-    const uint2* __restrict__ ranges, const float* __restrict__ stream, int W, int H, int gx, int geom_channels,
+    const uint2* __restrict__ ranges, const float* __restrict__ stream, int W, int H, int gx,
     const float* __restrict__ bg, const float* __restrict__ out_alpha, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha_map,
     float* __restrict__ grad_rec) {
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
 #pragma unroll
     for (int c = 0; c < C; ++c) {
         g[c] = inside ? dL_dcolor[c * plane + pix] : 0.f;
-        if (c < geom_channels) bg_dot += bg[c] * g[c];
+        if (c < GC) bg_dot += bg[c] * g[c];
     }
     const float gd = (inside && dL_ddepth) ? dL_ddepth[pix] : 0.f;
     const float ga = (inside && dL_dalpha_map) ? dL_dalpha_map[pix] : 0.f;
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 v[c] = w * g[c];
-                if (c < geom_channels) {
+                if (c < GC) {
                     const float diff = rec_j.feat(c) - R[c];
                     dL_dalpha += diff * g[c];
                     R[c] += al * diff;
@@ -205,12 +207,21 @@ __global__ void wave_fold16_test_kernel(const float* __restrict__ in, float* __r
 template <int C>
 int launch_c(const OgsRasterBwdArgs& a, const ImageState& is, float* grad_rec, hipStream_t s) {
     const int gx = (a.W + kTile - 1) / kTile, gy = (a.H + kTile - 1) / kTile;
-    const int geom_channels = (a.geom_channels > 0 && a.geom_channels < C) ? a.geom_channels : C;
     static constexpr const char* const kNames[4] = {"blend_backward_kernel<3>", "blend_backward_kernel<6>",
                                                     "blend_backward_kernel<9>", "blend_backward_kernel<12>"};
-    OGS_LAUNCH_NAMED(chan_name<C>(kNames), blend_backward_kernel<C>, dim3(gx * gy), dim3(kBlock), 0, s,
-                     (const uint2*)is.ranges, (const float*)stream_base<C>(const_cast<void*>(a.sorted_rec)), a.W, a.H, gx, geom_channels, a.bg, a.out_alpha,
-                     (const uint32_t*)is.n_contrib, a.dL_dcolor, a.dL_ddepth, a.dL_dalpha, grad_rec);
+    const float* stream = (const float*)stream_base<C>(const_cast<void*>(a.sorted_rec));
+    if (a.geom_channels <= 0 || a.geom_channels >= C) {
+        OGS_LAUNCH_NAMED(chan_name<C>(kNames), (blend_backward_kernel<C, C>), dim3(gx * gy), dim3(kBlock), 0, s,
+                         (const uint2*)is.ranges, stream, a.W, a.H, gx, a.bg, a.out_alpha, (const uint32_t*)is.n_contrib,
+                         a.dL_dcolor, a.dL_ddepth, a.dL_dalpha, grad_rec);
+    } else if (a.geom_channels == 3) {
+        OGS_LAUNCH_NAMED(chan_name<C>(kNames), (blend_backward_kernel<C, 3>), dim3(gx * gy), dim3(kBlock), 0, s,
+                         (const uint2*)is.ranges, stream, a.W, a.H, gx, a.bg, a.out_alpha, (const uint32_t*)is.n_contrib,
+                         a.dL_dcolor, a.dL_ddepth, a.dL_dalpha, grad_rec);
+    } else {
+        set_error("backward: geom_channels must be 0, 3 or C (got %d with C=%d)", a.geom_channels, C);
+        return OGS_ERR_UNSUPPORTED;
+    }
     OGS_LAUNCH_CHECK(a.debug, s);
     return OGS_OK;
 }

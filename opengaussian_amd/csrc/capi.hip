@@ -24,7 +24,7 @@ void set_error(const char* fmt, ...) {
 // ---- per-kernel timing ----------------------------------------------------------------------------------
 namespace {
 struct ProfRec { const char* name; hipEvent_t start, stop; };
-bool g_prof_on = false;
+int g_prof_mode = 0;     // 0 off, 1 every launch, 2 only the blend kernels (cheap enough for a timed region)
 std::vector<ProfRec> g_prof;
 std::vector<hipEvent_t> g_event_pool;
 std::mutex g_prof_mu;
@@ -37,7 +37,8 @@ hipEvent_t take_event() {
 }  // namespace
 
 ProfScope::ProfScope(const char* n, hipStream_t s) : name(n), stream(s), slot(-1) {
-    if (!g_prof_on) return;
+    if (g_prof_mode == 0) return;
+    if (g_prof_mode == 2 && strncmp(n, "blend_", 6) != 0) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfRec r{n, take_event(), take_event()};
     (void)hipEventRecord(r.start, s);
@@ -100,7 +101,7 @@ int ogs_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto& r : g_prof) { g_event_pool.push_back(r.start); g_event_pool.push_back(r.stop); }
     g_prof.clear();
-    g_prof_on = on != 0;
+    g_prof_mode = on;
     return OGS_OK;
 }
 
