@@ -212,7 +212,9 @@ def main():
 
     names_f = names_a + ["ins_feat"]
     fused = not (args.separate_passes or args.rgb_only)
-    bucket_f = dp.GradBucket([leaves[n].shape for n in names_f], device) if world > 1 and fused else None
+    # one flat SUM bucket: all per-Gaussian gradients + the two SUM-reducible densification statistics
+    bucket_f = (dp.GradBucket([leaves[n].shape for n in names_f] + [(2, P)], device, average=False)
+                if world > 1 and fused else None)
     gCF = torch.cat([gC, gF])
 
     def step_fused():
@@ -227,10 +229,12 @@ def main():
         info["D"] = color.grad_fn.num_rendered
         torch.autograd.backward([color, alpha], [gCF, gA])
         if bucket_f is not None:
-            bucket_f.pack([leaves[n].grad for n in names_f])
-            bucket_f.allreduce_async()
-            dp.reduce_densification_stats(m2.grad, radii)
+            bucket_f.pack([leaves[n].grad for n in names_f] + [dp.densification_stats(m2.grad, radii)])
+            bucket_f.allreduce_async()                                   # RCCL, side stream
+            rmax, work = dp.reduce_max_radii(radii, async_op=True)       # the one non-SUM statistic
             bucket_f.wait()
+            if work is not None:
+                work.wait()
         return radii
 
     def step():

@@ -90,6 +90,23 @@ class GradBucket:
         return self.views()
 
 
+def densification_stats(grad_means2D: torch.Tensor, radii: torch.Tensor) -> torch.Tensor:
+    """This view's [2, P] SUM-reducible statistics: row 0 = ||grad_means2D[:, :2]|| on visible Gaussians, row 1 =
+    visibility (0/1).  Append it to the gradient bucket so that it rides in the same all-reduce; MAX(radii) still
+    needs its own (tiny) collective -- see reduce_max_radii."""
+    vis = radii > 0
+    return torch.stack([torch.norm(grad_means2D[:, :2], dim=-1) * vis, vis.to(torch.float32)])
+
+
+def reduce_max_radii(radii: torch.Tensor, group=None, async_op: bool = False):
+    """MAX over views of the screen-space radii (train.py:597).  Returns (tensor, work-or-None)."""
+    rmax = radii.to(torch.int32).clone()
+    work = None
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        work = dist.all_reduce(rmax, op=dist.ReduceOp.MAX, group=group, async_op=async_op)
+    return rmax, work
+
+
 def reduce_densification_stats(grad_means2D: torch.Tensor, radii: torch.Tensor, group=None):
     """Per-view statistics that must be reduced separately from the gradients.
 

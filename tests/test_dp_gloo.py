@@ -52,6 +52,15 @@ def _worker(rank, world, port, q):
     exp_cnt = sum(((torch.arange(P) * (rr + 1) % 7) > 0).float() for rr in range(world))
     exp_max = torch.stack([(torch.arange(P) * (rr + 1) % 7) for rr in range(world)]).max(0)[0].to(torch.int32)
     ok = ok and torch.allclose(norm, exp_norm) and torch.allclose(cnt, exp_cnt) and torch.equal(rmax, exp_max)
+    # the same statistics riding inside a (non-averaged) SUM bucket + the separate MAX collective (bench.py's form)
+    b2 = dp.GradBucket([(2, P)], "cpu", average=False)
+    b2.pack([dp.densification_stats(m2, radii)])
+    b2.allreduce_async()
+    s = b2.wait()[0]
+    rm, work = dp.reduce_max_radii(radii, async_op=True)
+    if work is not None:
+        work.wait()
+    ok = ok and torch.allclose(s[0], exp_norm) and torch.allclose(s[1], exp_cnt) and torch.equal(rm, exp_max)
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
