@@ -140,11 +140,23 @@ size_t ogs_raster_sorted_bytes(int64_t num_rendered, int32_t C);
 
 /* Phase 1: fills radii + geom_buffer, leaves the depth order and tile offsets in geom_tmp, writes
  * num_rendered to *num_rendered_host (host memory) and returns after the stream has finished it
- * (the same blocking read-back the reference performs once per forward). */
+ * (the same blocking read-back the reference performs once per forward).
+ * num_rendered_host == NULL: no read-back, no synchronisation (see the deferred variant below). */
 int ogs_raster_forward_geometry(const OgsRasterFwdArgs* args, void* stream, int64_t* num_rendered_host);
 
-/* Phase 2: needs args->point_list / args->binning_tmp sized for num_rendered.  Asynchronous. */
+/* Phase 2: needs args->point_list / args->binning_tmp / args->sorted_rec sized for num_rendered.  Asynchronous. */
 int ogs_raster_forward_render(const OgsRasterFwdArgs* args, int64_t num_rendered, void* stream);
+
+/* Sync-free variant of the two calls above (removes the GPU idle gap of the read-back):
+ *   ogs_raster_forward_geometry(args, stream, NULL)            no copy, no synchronisation
+ *   ogs_raster_read_num_rendered_async(args, stream, pinned)   enqueue the 4-byte D2H copy into PINNED host memory
+ *   ogs_raster_forward_render_deferred(args, capacity, stream) buffers sized for `capacity` (e.g. 1.25x the last
+ *        num_rendered); the binning kernels read the true count from device memory, entries past the capacity
+ *        are dropped
+ * The caller waits for the copy (an event recorded after it), and if *pinned > capacity re-runs
+ * ogs_raster_forward_render with exact buffers -- the only case in which the deferred images are incomplete. */
+int ogs_raster_read_num_rendered_async(const OgsRasterFwdArgs* args, void* stream, uint32_t* host_pinned);
+int ogs_raster_forward_render_deferred(const OgsRasterFwdArgs* args, int64_t capacity, void* stream);
 
 /* Backward.  Asynchronous on `stream`. */
 int ogs_raster_backward(const OgsRasterBwdArgs* args, void* stream);

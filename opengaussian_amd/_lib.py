@@ -57,6 +57,8 @@ SIGNATURES = {
     "ogs_raster_sorted_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
     "ogs_raster_forward_geometry": (C.c_int, [C.POINTER(OgsRasterFwdArgs), _vp, C.POINTER(C.c_int64)]),
     "ogs_raster_forward_render": (C.c_int, [C.POINTER(OgsRasterFwdArgs), C.c_int64, _vp]),
+    "ogs_raster_read_num_rendered_async": (C.c_int, [C.POINTER(OgsRasterFwdArgs), _vp, _vp]),
+    "ogs_raster_forward_render_deferred": (C.c_int, [C.POINTER(OgsRasterFwdArgs), C.c_int64, _vp]),
     "ogs_raster_backward": (C.c_int, [C.POINTER(OgsRasterBwdArgs), _vp]),
     "ogs_mark_visible": (C.c_int, [C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "ogs_raster_export_binning": (C.c_int, [C.POINTER(OgsRasterFwdArgs), C.c_int64, _vp, _vp, _vp, _vp]),

@@ -106,9 +106,13 @@ __global__ void scan_total_kernel(const uint32_t* __restrict__ in, const uint32_
 inline int scan_blocks(int64_t n) { return (int)((n + kScanTile - 1) / kScanTile); }
 
 // ---- radix pass -----------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void radix_hist_kernel(const uint32_t* __restrict__ keys, int64_t n, int shift,
+// n_dev (optional): the element count lives in device memory (deferred render phase: the host sized the launch
+// for a capacity n_cap and has not read the true count back yet); workgroups past the true count see no elements.
+__global__ __launch_bounds__(kBlock) void radix_hist_kernel(const uint32_t* __restrict__ keys, int64_t n_cap,
+                                                            const uint32_t* __restrict__ n_dev, int shift,
                                                             int bits, uint32_t* __restrict__ hist, int nblocks) {
     __shared__ uint32_t h[256];
+    const int64_t n = n_dev ? min((int64_t)*n_dev, n_cap) : n_cap;
     const int ndig = 1 << bits;
     const uint32_t mask = ndig - 1;
     h[threadIdx.x] = 0;
@@ -126,11 +130,13 @@ __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const uint32_t* __re
 __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                                const uint32_t* __restrict__ vals_in,
                                                                uint32_t* __restrict__ keys_out,
-                                                               uint32_t* __restrict__ vals_out, int64_t n, int shift,
+                                                               uint32_t* __restrict__ vals_out, int64_t n_cap,
+                                                               const uint32_t* __restrict__ n_dev, int shift,
                                                                int bits, const uint32_t* __restrict__ offsets,
                                                                int nblocks) {
     __shared__ uint32_t wave_hist_s[kBlock / kWave][256];
     volatile uint32_t(*wave_hist)[256] = wave_hist_s;
+    const int64_t n = n_dev ? min((int64_t)*n_dev, n_cap) : n_cap;
     const int ndig = 1 << bits;
     const uint32_t mask = ndig - 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -193,8 +199,10 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint32_t* _
     }
 }
 
-__global__ __launch_bounds__(kBlock) void tile_ranges_kernel(const uint32_t* __restrict__ tile_keys, int64_t D,
+__global__ __launch_bounds__(kBlock) void tile_ranges_kernel(const uint32_t* __restrict__ tile_keys, int64_t D_cap,
+                                                             const uint32_t* __restrict__ n_dev,
                                                              uint2* __restrict__ ranges) {
+    const int64_t D = n_dev ? min((int64_t)*n_dev, D_cap) : D_cap;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= D) return;
     const uint32_t cur = tile_keys[i];
@@ -272,30 +280,32 @@ int exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out
     return OGS_OK;
 }
 
+// n is the element count, or -- when n_dev != nullptr -- the CAPACITY the launch is sized for while the true
+// count (<= capacity after clamping) is read from device memory by the kernels.
 int radix_pass(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, int64_t n,
-               int shift, int bits, void* tmp, hipStream_t stream, int debug) {
+               int shift, int bits, void* tmp, hipStream_t stream, int debug, const uint32_t* n_dev) {
     if (n <= 0) return OGS_OK;
     if (bits < 1 || bits > 8) { set_error("radix_pass: bits=%d out of range", bits); return OGS_ERR_INVALID_ARG; }
     const int nb = sort_blocks(n);
     const int ndig = 1 << bits;
     uint32_t* hist = static_cast<uint32_t*>(tmp);
     void* scan_tmp = static_cast<char*>(tmp) + align_up((size_t)256 * nb * sizeof(uint32_t));
-    OGS_LAUNCH(radix_hist_kernel, dim3(nb), dim3(kBlock), 0, stream, keys_in, n, shift, bits, hist, nb);
+    OGS_LAUNCH(radix_hist_kernel, dim3(nb), dim3(kBlock), 0, stream, keys_in, n, n_dev, shift, bits, hist, nb);
     OGS_LAUNCH_CHECK(debug, stream);
     int rc = exclusive_scan_u32(hist, nullptr, hist, (int64_t)ndig * nb, nullptr, scan_tmp, stream, debug);
     if (rc != OGS_OK) return rc;
-    OGS_LAUNCH(radix_scatter_kernel, dim3(nb), dim3(kBlock), 0, stream, keys_in, vals_in, keys_out, vals_out, n,
+    OGS_LAUNCH(radix_scatter_kernel, dim3(nb), dim3(kBlock), 0, stream, keys_in, vals_in, keys_out, vals_out, n, n_dev,
                        shift, bits, (const uint32_t*)hist, nb);
     OGS_LAUNCH_CHECK(debug, stream);
     return OGS_OK;
 }
 
 int launch_tile_ranges(const uint32_t* tile_keys_sorted, int64_t D, uint2* ranges, int tiles, hipStream_t s,
-                       int debug) {
+                       int debug, const uint32_t* n_dev) {
     OGS_HIP_CHECK(hipMemsetAsync(ranges, 0, (size_t)tiles * sizeof(uint2), s));
     if (D <= 0) return OGS_OK;
     const int grid = (int)((D + kBlock - 1) / kBlock);
-    OGS_LAUNCH(tile_ranges_kernel, dim3(grid), dim3(kBlock), 0, s, tile_keys_sorted, D, ranges);
+    OGS_LAUNCH(tile_ranges_kernel, dim3(grid), dim3(kBlock), 0, s, tile_keys_sorted, D, n_dev, ranges);
     OGS_LAUNCH_CHECK(debug, s);
     return OGS_OK;
 }

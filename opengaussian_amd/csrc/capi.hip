@@ -147,9 +147,8 @@ size_t ogs_raster_backward_tmp_bytes(int32_t P) { return align_up((size_t)(P > 0
 int ogs_raster_forward_geometry(const OgsRasterFwdArgs* a, void* stream_, int64_t* num_rendered_host) {
     int rc = validate_fwd(a);
     if (rc != OGS_OK) return rc;
-    if (!num_rendered_host) { set_error("num_rendered_host == NULL"); return OGS_ERR_INVALID_ARG; }
     hipStream_t s = static_cast<hipStream_t>(stream_);
-    *num_rendered_host = 0;
+    if (num_rendered_host) *num_rendered_host = 0;
     if (a->P == 0) return OGS_OK;
     const GeomState gs = GeomState::carve(a->geom_buffer, a->P, a->C);
     const GeomTmp gt = GeomTmp::carve(a->geom_tmp, a->P);
@@ -164,17 +163,29 @@ int ogs_raster_forward_geometry(const OgsRasterFwdArgs* a, void* stream_, int64_
     // offsets[r] = exclusive scan of tiles_touched in depth order; total = num_rendered
     rc = exclusive_scan_u32(gt.tiles_touched, gt.order[0], gt.offsets, a->P, gt.num_rendered, gt.sort_tmp, s, a->debug);
     if (rc != OGS_OK) return rc;
-    uint32_t d = 0;
-    OGS_HIP_CHECK(hipMemcpyAsync(&d, gt.num_rendered, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    OGS_HIP_CHECK(hipStreamSynchronize(s));
-    *num_rendered_host = (int64_t)d;
+    if (num_rendered_host) {       // blocking read-back (what the reference does once per forward)
+        uint32_t d = 0;
+        OGS_HIP_CHECK(hipMemcpyAsync(&d, gt.num_rendered, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        OGS_HIP_CHECK(hipStreamSynchronize(s));
+        *num_rendered_host = (int64_t)d;
+    }
     return OGS_OK;
 }
 
-int ogs_raster_forward_render(const OgsRasterFwdArgs* a, int64_t D, void* stream_) {
+int ogs_raster_read_num_rendered_async(const OgsRasterFwdArgs* a, void* stream_, uint32_t* host_pinned) {
+    if (!a || !host_pinned) { set_error("read_num_rendered_async: NULL pointer"); return OGS_ERR_INVALID_ARG; }
+    if (a->P == 0) { *host_pinned = 0; return OGS_OK; }
+    const GeomTmp gt = GeomTmp::carve(a->geom_tmp, a->P);
+    OGS_HIP_CHECK(hipMemcpyAsync(host_pinned, gt.num_rendered, sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                 static_cast<hipStream_t>(stream_)));
+    return OGS_OK;
+}
+
+// D = exact num_rendered (deferred == false) or the CAPACITY of point_list / binning_tmp / sorted_rec while the
+// binning kernels read the true count from device memory (deferred == true).
+static int render_impl(const OgsRasterFwdArgs* a, int64_t D, bool deferred, hipStream_t s) {
     int rc = validate_fwd(a);
     if (rc != OGS_OK) return rc;
-    hipStream_t s = static_cast<hipStream_t>(stream_);
     const ImageState is = ImageState::carve(a->image_buffer, a->W, a->H);
     const int gx = (a->W + kTile - 1) / kTile, gy = (a->H + kTile - 1) / kTile;
     const int tiles = gx * gy;
@@ -191,22 +202,32 @@ int ogs_raster_forward_render(const OgsRasterFwdArgs* a, int64_t D, void* stream
         uint32_t* vbuf[2];
         vbuf[passes & 1] = a->point_list;        // buffer index after `passes` flips from 0
         vbuf[(passes & 1) ^ 1] = bt.vals;
-        rc = launch_duplicate(*a, gs, gt, bt.tile_keys[0], vbuf[0], s);
+        const uint32_t* n_dev = deferred ? gt.num_rendered : nullptr;
+        rc = launch_duplicate(*a, gs, gt, bt.tile_keys[0], vbuf[0], (uint32_t)D, s);
         if (rc != OGS_OK) return rc;
         for (int p = 0; p < passes; ++p) {
             const int in = p & 1, out = in ^ 1;
             const int shift = p * per;
             const int nb = (p == passes - 1) ? (bits == 0 ? 1 : bits - shift) : per;
-            rc = radix_pass(bt.tile_keys[in], vbuf[in], bt.tile_keys[out], vbuf[out], D, shift, nb, bt.sort_tmp, s, a->debug);
+            rc = radix_pass(bt.tile_keys[in], vbuf[in], bt.tile_keys[out], vbuf[out], D, shift, nb, bt.sort_tmp, s, a->debug, n_dev);
             if (rc != OGS_OK) return rc;
         }
-        rc = launch_tile_ranges(bt.tile_keys[passes & 1], D, is.ranges, tiles, s, a->debug);
+        rc = launch_tile_ranges(bt.tile_keys[passes & 1], D, is.ranges, tiles, s, a->debug, n_dev);
         if (rc != OGS_OK) return rc;
     } else {
         OGS_HIP_CHECK(hipMemsetAsync(is.ranges, 0, (size_t)tiles * sizeof(uint2), s));
     }
     if (D > 0 && !a->sorted_rec) { set_error("sorted_rec == NULL with num_rendered=%lld", (long long)D); return OGS_ERR_INVALID_ARG; }
     return launch_blend_forward(*a, gs, is, D, s);
+}
+
+int ogs_raster_forward_render(const OgsRasterFwdArgs* a, int64_t D, void* stream_) {
+    return render_impl(a, D, false, static_cast<hipStream_t>(stream_));
+}
+
+int ogs_raster_forward_render_deferred(const OgsRasterFwdArgs* a, int64_t capacity, void* stream_) {
+    if (capacity <= 0) { set_error("forward_render_deferred: capacity must be > 0"); return OGS_ERR_INVALID_ARG; }
+    return render_impl(a, capacity, true, static_cast<hipStream_t>(stream_));
 }
 
 int ogs_raster_backward(const OgsRasterBwdArgs* a, void* stream_) {

@@ -179,7 +179,8 @@ int exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out
                        uint32_t* total, void* tmp, hipStream_t stream, int debug);
 // One stable LSD pass on bits [shift, shift+bits) of keys_in (bits <= 8).
 int radix_pass(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
-               int64_t n, int shift, int bits, void* tmp, hipStream_t stream, int debug);
+               int64_t n, int shift, int bits, void* tmp, hipStream_t stream, int debug,
+               const uint32_t* n_dev = nullptr);
 
 struct GeomTmp {        // transient, but must survive from forward_geometry to forward_render
     uint32_t* tiles_touched;   // [P]
@@ -234,9 +235,9 @@ struct BinTmp {         // transient, render phase
 // kernels launched by capi.hip ------------------------------------------------------------------
 int launch_preprocess(const OgsRasterFwdArgs& a, const GeomState& gs, const GeomTmp& gt, hipStream_t s);
 int launch_duplicate(const OgsRasterFwdArgs& a, const GeomState& gs, const GeomTmp& gt, uint32_t* tile_keys,
-                     uint32_t* vals, hipStream_t s);
+                     uint32_t* vals, uint32_t capacity, hipStream_t s);
 int launch_tile_ranges(const uint32_t* tile_keys_sorted, int64_t D, uint2* ranges, int tiles, hipStream_t s,
-                       int debug);
+                       int debug, const uint32_t* n_dev = nullptr);
 int launch_blend_forward(const OgsRasterFwdArgs& a, const GeomState& gs, const ImageState& is, int64_t D,
                          hipStream_t s);
 int launch_blend_backward(const OgsRasterBwdArgs& a, const ImageState& is, float* grad_rec, hipStream_t s);

@@ -246,7 +246,9 @@ __global__ __launch_bounds__(kBlock) void duplicate_kernel(int P, int W, int H, 
                                                            const uint32_t* __restrict__ order,
                                                            const uint32_t* __restrict__ offsets,
                                                            uint32_t* __restrict__ tile_keys,
-                                                           uint32_t* __restrict__ vals) {
+                                                           uint32_t* __restrict__ vals, uint32_t capacity) {
+    // capacity: size of tile_keys / vals.  In the deferred render phase it is a cached estimate and the true
+    // num_rendered may exceed it: such entries are dropped here and the host re-runs the phase (rasterizer.py).
     const int r = blockIdx.x * kBlock + threadIdx.x;
     if (r >= P) return;
     const uint32_t gid = order[r];
@@ -267,8 +269,10 @@ __global__ __launch_bounds__(kBlock) void duplicate_kernel(int P, int W, int H, 
     uint32_t off = offsets[r];
     for (int ty = rminy; ty < rmaxy; ++ty)
         for (int tx = rminx; tx < rmaxx; ++tx) {
-            tile_keys[off] = (uint32_t)(ty * gx + tx);
-            vals[off] = gid;
+            if (off < capacity) {
+                tile_keys[off] = (uint32_t)(ty * gx + tx);
+                vals[off] = gid;
+            }
             ++off;
         }
 }
@@ -310,12 +314,12 @@ int launch_preprocess(const OgsRasterFwdArgs& a, const GeomState& gs, const Geom
 }
 
 int launch_duplicate(const OgsRasterFwdArgs& a, const GeomState& gs, const GeomTmp& gt, uint32_t* tile_keys,
-                     uint32_t* vals, hipStream_t s) {
+                     uint32_t* vals, uint32_t capacity, hipStream_t s) {
     const int grid = (a.P + kBlock - 1) / kBlock;
     switch (rec_vec4(a.C)) {
-        case 3: OGS_LAUNCH(duplicate_kernel<3>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals); break;
-        case 4: OGS_LAUNCH(duplicate_kernel<4>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals); break;
-        case 5: OGS_LAUNCH(duplicate_kernel<5>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals); break;
+        case 3: OGS_LAUNCH(duplicate_kernel<3>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals, capacity); break;
+        case 4: OGS_LAUNCH(duplicate_kernel<4>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals, capacity); break;
+        case 5: OGS_LAUNCH(duplicate_kernel<5>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals, capacity); break;
         default: set_error("unsupported record size"); return OGS_ERR_UNSUPPORTED;
     }
     OGS_LAUNCH_CHECK(a.debug, s);

@@ -24,6 +24,8 @@ from . import _lib
 from ._lib import OgsRasterBwdArgs, OgsRasterFwdArgs, check, ptr
 
 SUPPORTED_CHANNELS = (3, 6, 9, 12)
+# (P, W, H) -> num_rendered of the last pass at that size: capacity hint of the sync-free render phase
+_LAST_NUM_RENDERED: dict = {}
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -126,14 +128,44 @@ class _RasterizeGaussians(torch.autograd.Function):
         a.geom_buffer, a.geom_tmp, a.image_buffer = ptr(geom), ptr(geom_tmp), ptr(image)
 
         stream = _stream()
-        n = C.c_int64(0)
-        check(lib.ogs_raster_forward_geometry(C.byref(a), stream, C.byref(n)), "ogs_raster_forward_geometry")
-        D = int(n.value)
-        point_list = torch.empty(max(D, 1), dtype=torch.int32, device=dev)
-        bin_tmp = u8(lib.ogs_raster_binning_tmp_bytes(D, W, H))
-        sorted_rec = u8(lib.ogs_raster_sorted_bytes(D, Cn))
-        a.point_list, a.binning_tmp, a.sorted_rec = ptr(point_list), ptr(bin_tmp), ptr(sorted_rec)
-        check(lib.ogs_raster_forward_render(C.byref(a), D, stream), "ogs_raster_forward_render")
+
+        def alloc_render(count):
+            pl = torch.empty(max(count, 1), dtype=torch.int32, device=dev)
+            bt = u8(lib.ogs_raster_binning_tmp_bytes(count, W, H))
+            sr = u8(lib.ogs_raster_sorted_bytes(count, Cn))
+            a.point_list, a.binning_tmp, a.sorted_rec = ptr(pl), ptr(bt), ptr(sr)
+            return pl, bt, sr
+
+        key = (P, W, H)
+        last = _LAST_NUM_RENDERED.get(key)
+        if last is None or rs.debug:
+            # first pass at this size: blocking 4-byte read-back of num_rendered (what the reference does every time)
+            n = C.c_int64(0)
+            check(lib.ogs_raster_forward_geometry(C.byref(a), stream, C.byref(n)), "ogs_raster_forward_geometry")
+            D = int(n.value)
+            point_list, bin_tmp, sorted_rec = alloc_render(D)
+            check(lib.ogs_raster_forward_render(C.byref(a), D, stream), "ogs_raster_forward_render")
+        else:
+            # steady state: no GPU idle gap.  The render phase is enqueued for a capacity derived from the last
+            # pass at this size; the true count arrives through an async pinned copy and is only WAITED for after
+            # everything is queued.  Overflow (scene changed a lot) -> redo the render phase with exact buffers.
+            check(lib.ogs_raster_forward_geometry(C.byref(a), stream, None), "ogs_raster_forward_geometry")
+            pinned = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            check(lib.ogs_raster_read_num_rendered_async(C.byref(a), stream, pinned.data_ptr()),
+                  "ogs_raster_read_num_rendered_async")
+            ev = torch.cuda.Event()
+            ev.record()
+            cap = int(last * 1.25) + 4096
+            point_list, bin_tmp, sorted_rec = alloc_render(cap)
+            check(lib.ogs_raster_forward_render_deferred(C.byref(a), cap, stream), "ogs_raster_forward_render_deferred")
+            ev.synchronize()
+            D = int(pinned.item()) & 0xFFFFFFFF
+            if D > cap:
+                point_list, bin_tmp, sorted_rec = alloc_render(D)
+                check(lib.ogs_raster_forward_render(C.byref(a), D, stream), "ogs_raster_forward_render")
+        if len(_LAST_NUM_RENDERED) > 256:      # subset renders come in many sizes: keep the hint table small
+            _LAST_NUM_RENDERED.clear()
+        _LAST_NUM_RENDERED[key] = D
 
         ctx.num_rendered = D
         ctx.save_for_backward(m3, shs, cols, opac, scl, rot, cov, bg, view, proj, campos, radii, alpha, geom, image,

@@ -186,6 +186,36 @@ def test_fused_pass_equals_separate_passes(gpu_device):
     assert float((m2.grad - m2f.grad).abs().max()) / scale < 1e-4
 
 
+def test_deferred_render_phase_and_capacity_overflow(gpu_device):
+    """Second and later passes at one size skip the blocking num_rendered read-back (capacity from the previous
+    pass).  Results must not depend on the path taken: first pass (blocking), steady state (deferred), and a
+    forced capacity overflow (deferred result discarded, render phase redone with exact buffers)."""
+    from opengaussian_amd import rasterizer as R
+    W, H, f = 160, 96, 120.0
+    sc, cam = helpers.tiny_scene(2500, W, H, f, seed=31)
+    inp = helpers.oracle_inputs(sc, cam, use_sh=True)
+    key = (2500, W, H)
+    R._LAST_NUM_RENDERED.pop(key, None)
+    (c0, r0, d0, a0), _ = helpers.hip_forward(inp, cam, (0.1, 0.2, 0.3), 3, gpu_device, requires_grad=True)
+    D = R._LAST_NUM_RENDERED[key]
+    assert D == c0.grad_fn.num_rendered > 0
+    (c1, r1, d1, a1), _ = helpers.hip_forward(inp, cam, (0.1, 0.2, 0.3), 3, gpu_device, requires_grad=True)   # deferred
+    R._LAST_NUM_RENDERED[key] = 7                                                                         # overflow
+    (c2, r2, d2, a2), _ = helpers.hip_forward(inp, cam, (0.1, 0.2, 0.3), 3, gpu_device, requires_grad=True)
+    assert R._LAST_NUM_RENDERED[key] == D and c2.grad_fn.num_rendered == D
+    for c, r, d, a in ((c1, r1, d1, a1), (c2, r2, d2, a2)):
+        assert torch.equal(c, c0) and torch.equal(r, r0) and torch.equal(d, d0) and torch.equal(a, a0)
+    k0 = helpers.hip_export_binning(c0)
+    for cc in (c1, c2):
+        k = helpers.hip_export_binning(cc)
+        for x, y in zip(k0, k):
+            np.testing.assert_array_equal(x, y)
+    # and the backward pass works off either
+    g = torch.ones_like(c0)
+    for cc in (c1, c2):
+        cc.backward(g)
+
+
 def test_noncontiguous_inputs(gpu_device):
     """render() feeds sliced / boolean-indexed views (gaussian_renderer/__init__.py:133,204-212)."""
     from opengaussian_amd.rasterizer import GaussianRasterizer
