@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kBlock) void kmeans_lds_pass_kernel(const float* __
 
 // Stage 1 of the cross-workgroup reduction: slice s of the partial tables -> slices[s][stride]; every element is
 // summed in block order inside its slice (deterministic).
-constexpr int kSlices = 16;
+constexpr int kSlices = 64;
 __global__ __launch_bounds__(kBlock) void kmeans_reduce_kernel(const float* __restrict__ partials, int nblocks,
                                                                int stride, float* __restrict__ slices) {
     const int e = blockIdx.x * kBlock + threadIdx.x;
