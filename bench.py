@@ -50,6 +50,12 @@ def parse():
     ap.add_argument("--cpu-tile-stride", type=int, default=8, help="CPU baseline renders this many full tile rows")
     ap.add_argument("--no-kmeans", action="store_true")
     ap.add_argument("--rgb-only", action="store_true", help="time pass A only (BASELINE.md row 'RGB')")
+    ap.add_argument("--exchange", default="pipelined", choices=["pipelined", "sync"],
+                    help="N > 1: 'pipelined' = the gradient exchange of view i overlaps the render of view i+1 on the "
+                         "same rank (double-buffered buckets; every exchange still completes inside the timed "
+                         "region); 'sync' = each step waits for its own exchange before the next render starts")
+    ap.add_argument("--dense-sh-allreduce", action="store_true",
+                    help="N > 1: all-reduce the dense [P,16,3] SH gradient instead of all-gathering its rank-1 factor")
     ap.add_argument("--separate-passes", action="store_true",
                     help="render RGB and the 6-ch ins_feat map as two rasterizer passes (reference structure) "
                          "instead of the single fused 9-channel pass")
@@ -212,10 +218,34 @@ def main():
 
     names_f = names_a + ["ins_feat"]
     fused = not (args.separate_passes or args.rgb_only)
-    # one flat SUM bucket: all per-Gaussian gradients + the two SUM-reducible densification statistics
-    bucket_f = (dp.GradBucket([leaves[n].shape for n in names_f] + [(2, P)], device, average=False)
-                if world > 1 and fused else None)
+    # N > 1 exchange per step (dp.py): ONE flat SUM bucket (per-Gaussian gradients + the two SUM-reducible
+    # densification statistics), an all-gather of the [P,3] rank-1 factor of the SH gradient (rebuilt locally by
+    # ogs_sh_grad_from_views: 4x fewer xGMI bytes than all-reducing [P,16,3]), and a MAX all-reduce of the radii.
+    compress_sh = world > 1 and fused and not args.dense_sh_allreduce
+    names_x = [n for n in names_f if not (compress_sh and n == "shs")]
+    nsets = 2 if args.exchange == "pipelined" else 1
+    sets = []
+    if world > 1 and fused:
+        for _ in range(nsets):
+            sets.append(dict(bucket=dp.GradBucket([leaves[n].shape for n in names_x] + [(2, P)], device, average=False),
+                             sh=dp.ShGradExchange(P, 16, device) if compress_sh else None,
+                             dsh=torch.empty(P, 16, 3, device=device) if compress_sh else None,
+                             pending=False, radii_work=None))
+        campos_all = torch.stack([orbit_camera(W, H, f, f, view_index=r, num_views=world).camera_center
+                                  for r in range(world)]).to(device)
     gCF = torch.cat([gC, gF])
+    info["i"] = 0
+
+    def finish(st):
+        """make the reduced gradients of one exchange ready on the compute stream (what an optimizer would read)"""
+        if not st["pending"]:
+            return
+        st["bucket"].wait()
+        if st["sh"] is not None:
+            st["sh"].rebuild(leaves["means3D"], campos_all, 3, out=st["dsh"])
+        if st["radii_work"] is not None:
+            st["radii_work"].wait()
+        st["pending"] = False
 
     def step_fused():
         """ONE rasterization pass: RGB (SH) in channels 0..2, ins_feat in 3..8; the feature loss is detached
@@ -223,19 +253,30 @@ def main():
         for v in leaves.values():
             v.grad = None
         m2 = torch.zeros(P, 3, device=device, requires_grad=True)
+        sink = [] if compress_sh else None
         color, radii, depth, alpha = rasterize_fused(leaves["means3D"], m2, leaves["opacities"], leaves["shs"],
                                                      leaves["ins_feat"], settings, scales=leaves["scales"],
-                                                     rotations=leaves["rotations"])
+                                                     rotations=leaves["rotations"], sh_rgb_sink=sink)
         info["D"] = color.grad_fn.num_rendered
         torch.autograd.backward([color, alpha], [gCF, gA])
-        if bucket_f is not None:
-            bucket_f.pack([leaves[n].grad for n in names_f] + [dp.densification_stats(m2.grad, radii)])
-            bucket_f.allreduce_async()                                   # RCCL, side stream
-            rmax, work = dp.reduce_max_radii(radii, async_op=True)       # the one non-SUM statistic
-            bucket_f.wait()
-            if work is not None:
-                work.wait()
+        if sets:
+            i = info["i"]
+            info["i"] = i + 1
+            st = sets[i % nsets]
+            st["bucket"].pack([leaves[n].grad for n in names_x] + [dp.densification_stats(m2.grad, radii)])
+            st["bucket"].allreduce_async()                               # RCCL, side stream
+            if st["sh"] is not None:
+                st["sh"].gather_async(sink[0])
+            st["rmax"], st["radii_work"] = dp.reduce_max_radii(radii, async_op=True)   # the one non-SUM statistic
+            st["pending"] = True
+            # pipelined: this step's exchange keeps running while the NEXT render is enqueued; the previous
+            # step's exchange (which overlapped this render) is completed now
+            finish(sets[(i - 1) % nsets] if nsets == 2 else st)
         return radii
+
+    def drain():
+        for st in sets:
+            finish(st)
 
     def step():
         if fused:
@@ -273,6 +314,7 @@ def main():
 
     for i in range(args.warmup):
         radii = step()
+        drain()
         torch.cuda.synchronize()
         log(f"warmup step {i} done (D={info.get('D')})")
     barrier()
@@ -283,6 +325,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         radii = step()
+    drain()                                   # the last exchange(s) complete inside the timed region
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -292,6 +335,7 @@ def main():
     _lib.prof_enable(1)
     for _ in range(args.steps):
         step()
+    drain()
     torch.cuda.synchronize()
     prof_all = _lib.prof_collect()
     _lib.prof_enable(0)
@@ -344,7 +388,12 @@ def main():
                                                     (" RGB(SH3)+depth+alpha (all grads) + 6-ch ins_feat (grad to ins_feat) fwd+bwd, " +
                                                      ("ONE fused 9-channel pass" if fused else "two passes (3ch SH + 6ch)"))),
                        "gaussians": P, "width": W, "height": H, "views_per_step": world,
-                       "parallelism": f"view-dp{world}" if world > 1 else "single"},
+                       "parallelism": (f"view-dp{world}: one view per GPU, Gaussians replicated; per step one SUM "
+                                       f"all-reduce of the per-Gaussian gradients, "
+                                       + ("all-gather of the rank-1 SH-gradient factor, " if compress_sh else "")
+                                       + f"MAX all-reduce of radii; exchange {args.exchange}"
+                                       + (" (overlaps the next view's render; all exchanges complete in the timed region)"
+                                          if args.exchange == "pipelined" else "")) if world > 1 else "single"},
             "scene": {"P_visible": p_vis, "D_num_rendered": D, "mean_tile_list": D / gxy},
             "roofline": roofline,
             "step_algorithmic_GBps": step_bytes / (ms_per_step * 1e-3) / 1e9,

@@ -126,6 +126,11 @@ typedef struct OgsRasterBwdArgs {
     float* dL_dsh;               /* [P,M,3] (when shs was the input) */
     float* dL_dscales;           /* [P,3] */
     float* dL_drotations;        /* [P,4] */
+    float* dL_dsh_rgb;           /* [P,3] optional (shs input only): gradient w.r.t. the SH-evaluated RGB after the
+                                    clamp mask, zero for culled Gaussians.  Per view dL/dsh[p,m,:] = Y_m(dir(p)) *
+                                    dL_dsh_rgb[p,:] (rank 1), so a data-parallel caller can pass dL_dsh = NULL,
+                                    exchange these 3 floats instead of 3*M and rebuild the sum over views with
+                                    ogs_sh_grad_from_views().  dL_dmeans3D still includes the view-direction term. */
 } OgsRasterBwdArgs;
 
 int ogs_version(void);
@@ -165,6 +170,16 @@ int ogs_raster_backward(const OgsRasterBwdArgs* args, void* stream);
  * p_view.z > 0.2 (SURVEY.md section 2.1 `checkFrustum`). `present` is uint8[P]. */
 int ogs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* present, void* stream);
+
+/* Data-parallel helper (new capability; no reference counterpart): rebuilds
+ *   dL_dsh[p,m,c] = sum_v Y_m((means3D[p] - campos[v]) / |.|) * dL_drgb[v,p,c]
+ * i.e. the SUM over V views of the dL/dsh each view's backward would have written, from the per-view [P,3]
+ * colour gradients (OgsRasterBwdArgs.dL_dsh_rgb, all-gathered over the ranks) and the V camera centres.
+ * Exchanging 3 floats per Gaussian and view instead of all-reducing 3*M (48 at degree 3) cuts the xGMI bytes of
+ * the SH gradient ~4x at 8 GPUs and fixes the summation order (v = 0..V-1), so the result is deterministic.
+ * campos [V,3], dL_drgb [V,P,3], dL_dsh [P,sh_coeffs,3] (coefficients >= (sh_degree+1)^2 are written as 0). */
+int ogs_sh_grad_from_views(int32_t P, int32_t V, int32_t sh_degree, int32_t sh_coeffs, const float* means3D,
+                           const float* campos, const float* dL_drgb, float* dL_dsh, void* stream);
 
 /* Test/diagnostic export of the binning state the reference keeps in its binningBuffer /
  * imgBuffer: the sorted 64-bit keys (tile << 32 | float_bits(depth)) [num_rendered], the per-tile

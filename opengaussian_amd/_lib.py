@@ -41,7 +41,7 @@ class OgsRasterBwdArgs(C.Structure):
         ("radii", _vp), ("out_alpha", _vp), ("dL_dcolor", _vp), ("dL_ddepth", _vp), ("dL_dalpha", _vp),
         ("geom_buffer", _vp), ("image_buffer", _vp), ("point_list", _vp), ("sorted_rec", _vp), ("bwd_tmp", _vp),
         ("dL_dmeans2D", _vp), ("dL_dcolors", _vp), ("dL_dopacity", _vp), ("dL_dmeans3D", _vp),
-        ("dL_dcov3D", _vp), ("dL_dsh", _vp), ("dL_dscales", _vp), ("dL_drotations", _vp),
+        ("dL_dcov3D", _vp), ("dL_dsh", _vp), ("dL_dscales", _vp), ("dL_drotations", _vp), ("dL_dsh_rgb", _vp),
     ]
 
 
@@ -61,6 +61,7 @@ SIGNATURES = {
     "ogs_raster_forward_render_deferred": (C.c_int, [C.POINTER(OgsRasterFwdArgs), C.c_int64, _vp]),
     "ogs_raster_backward": (C.c_int, [C.POINTER(OgsRasterBwdArgs), _vp]),
     "ogs_mark_visible": (C.c_int, [C.c_int32, _vp, _vp, _vp, _vp, _vp]),
+    "ogs_sh_grad_from_views": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "ogs_raster_export_binning": (C.c_int, [C.POINTER(OgsRasterFwdArgs), C.c_int64, _vp, _vp, _vp, _vp]),
     "ogs_selftest_wave_fold16": (C.c_int, [_vp, _vp, _vp]),
     "ogs_prof_enable": (C.c_int, [C.c_int]),

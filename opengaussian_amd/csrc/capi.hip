@@ -257,6 +257,18 @@ int ogs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, c
     return launch_mark_visible(P, means3D, viewmatrix, present, static_cast<hipStream_t>(stream_));
 }
 
+int ogs_sh_grad_from_views(int32_t P, int32_t V, int32_t sh_degree, int32_t sh_coeffs, const float* means3D,
+                           const float* campos, const float* dL_drgb, float* dL_dsh, void* stream_) {
+    if (P == 0) return OGS_OK;
+    if (P < 0 || V < 1 || sh_degree < 0 || sh_degree > 3 || sh_coeffs < (sh_degree + 1) * (sh_degree + 1)) {
+        set_error("sh_grad_from_views: bad sizes P=%d V=%d degree=%d coeffs=%d", P, V, sh_degree, sh_coeffs);
+        return OGS_ERR_INVALID_ARG;
+    }
+    if (!means3D || !campos || !dL_drgb || !dL_dsh) { set_error("sh_grad_from_views: NULL pointer"); return OGS_ERR_INVALID_ARG; }
+    return launch_sh_grad_from_views(P, V, sh_degree, sh_coeffs, means3D, campos, dL_drgb, dL_dsh,
+                                     static_cast<hipStream_t>(stream_));
+}
+
 /* test hook (not part of the reference boundary): the wave64 16-slot transposed reduction used by the
  * backward blend.  in: [64][16] floats, out: [64]; out[lane] must equal sum_l in[l][lane>>2]. */
 int ogs_selftest_wave_fold16(const float* in, float* out, void* stream_) {

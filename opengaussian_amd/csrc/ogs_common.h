@@ -243,6 +243,8 @@ int launch_blend_forward(const OgsRasterFwdArgs& a, const GeomState& gs, const I
 int launch_blend_backward(const OgsRasterBwdArgs& a, const ImageState& is, float* grad_rec, hipStream_t s);
 int launch_preprocess_backward(const OgsRasterBwdArgs& a, const GeomState& gs, const float* grad_rec,
                                hipStream_t s);
+int launch_sh_grad_from_views(int P, int V, int sh_degree, int sh_coeffs, const float* means3D, const float* campos,
+                              const float* dL_drgb, float* dL_dsh, hipStream_t s);
 int launch_wave_fold16_test(const float* in, float* out, hipStream_t s);
 int launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
 int launch_export_keys(const uint2* ranges, int tiles, const uint32_t* point_list, const float4* rec, int recv4,

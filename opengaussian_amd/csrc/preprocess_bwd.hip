@@ -28,7 +28,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
     const int32_t* __restrict__ radii, const uint32_t* __restrict__ clamped_in, const float* __restrict__ grad_rec,
     float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
-    float* __restrict__ dL_dscales, float* __restrict__ dL_drotations) {
+    float* __restrict__ dL_dscales, float* __restrict__ dL_drotations, float* __restrict__ dL_dsh_rgb) {
     constexpr int GS = grad_stride(C);
     const int idx = blockIdx.x * kBlock + threadIdx.x;
     if (idx >= P) return;
@@ -65,7 +65,8 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
     float dscale[3] = {0.f, 0.f, 0.f};
     float drot[4] = {0.f, 0.f, 0.f, 0.f};
 
-    const bool need_geom = dL_dmeans3D || dL_dcov3D || dL_dscales || dL_drotations || dL_dsh;
+    const bool need_geom = dL_dmeans3D || dL_dcov3D || dL_dscales || dL_drotations || dL_dsh || dL_dsh_rgb;
+    float drgb_out[3] = {0.f, 0.f, 0.f};
     if (vis && need_geom) {
         float V[16], M[16];
 #pragma unroll
@@ -170,12 +171,13 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
         for (int i = 0; i < 3; ++i) dmean[i] += V[4 * i + 2] * d_depth;
 
         // ---- colour -> SH, view direction -> mean ---------------------------------------------------------
-        if (shs != nullptr && dL_dsh != nullptr) {
+        if (shs != nullptr && (dL_dsh != nullptr || dL_dsh_rgb != nullptr || dL_dmeans3D != nullptr)) {
             {
                 const uint32_t cl = clamped_in[idx];
                 const float dRGB[3] = {(cl & 1u) ? 0.f : gr[0], (cl & 2u) ? 0.f : gr[1], (cl & 4u) ? 0.f : gr[2]};
+                drgb_out[0] = dRGB[0]; drgb_out[1] = dRGB[1]; drgb_out[2] = dRGB[2];
                 const float* sh = shs + (size_t)idx * sh_coeffs * 3;
-                float* dsh = dL_dsh + (size_t)idx * sh_coeffs * 3;
+                float* dsh = dL_dsh ? dL_dsh + (size_t)idx * sh_coeffs * 3 : nullptr;
                 const float ox = x - campos[0], oy = y - campos[1], oz = z - campos[2];
                 const float il = rsqrtf(ox * ox + oy * oy + oz * oz);
                 const float dxn = ox * il, dyn = oy * il, dzn = oz * il;
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
                     // basis value -> dL/dsh[k]; basis gradient (bx,by,bz) * sh[k] -> dL/ddir
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch) {
-                        dsh[3 * k + ch] = basis * dRGB[ch];
+                        if (dsh) dsh[3 * k + ch] = basis * dRGB[ch];
                         const float s = sh[3 * k + ch] * dRGB[ch];
                         ddir[0] += bx * s; ddir[1] += by * s; ddir[2] += bz * s;
                     }
@@ -217,7 +219,8 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
                     }
                 }
                 const int used = (sh_degree + 1) * (sh_degree + 1);
-                for (int k = used; k < sh_coeffs; ++k) { dsh[3 * k] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f; }
+                if (dsh)
+                    for (int k = used; k < sh_coeffs; ++k) { dsh[3 * k] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f; }
                 // d(dir/|dir|)/d(dir) = (I - n n^T) / |dir|
                 const float nd = dxn * ddir[0] + dyn * ddir[1] + dzn * ddir[2];
                 dmean[0] += (ddir[0] - dxn * nd) * il;
@@ -259,6 +262,9 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
         for (int k = 0; k < sh_coeffs * 3; ++k) dsh[k] = 0.f;
     }
 
+    if (dL_dsh_rgb) {
+        dL_dsh_rgb[3 * idx] = drgb_out[0]; dL_dsh_rgb[3 * idx + 1] = drgb_out[1]; dL_dsh_rgb[3 * idx + 2] = drgb_out[2];
+    }
     if (dL_dmeans3D) {
         dL_dmeans3D[3 * idx] = dmean[0]; dL_dmeans3D[3 * idx + 1] = dmean[1]; dL_dmeans3D[3 * idx + 2] = dmean[2];
     }
@@ -284,12 +290,82 @@ int launch_c(const OgsRasterBwdArgs& a, const GeomState& gs, const float* grad_r
                        a.sh_coeffs, a.tanfovx, a.tanfovy, focal_x, focal_y, a.scale_modifier, a.means3D, a.shs, a.scales,
                        a.rotations, a.cov3D_precomp, a.viewmatrix, a.projmatrix, a.campos, a.radii,
                        (const uint32_t*)gs.clamped, grad_rec, a.dL_dmeans2D, a.dL_dcolors, a.dL_dopacity, a.dL_dmeans3D,
-                       a.dL_dcov3D, a.dL_dsh, a.dL_dscales, a.dL_drotations);
+                       a.dL_dcov3D, a.dL_dsh, a.dL_dscales, a.dL_drotations, a.dL_dsh_rgb);
     OGS_LAUNCH_CHECK(a.debug, s);
     return OGS_OK;
 }
 
+// SH basis values Y_0..Y_15 of a unit direction (same polynomials, constants and evaluation order as the emit()
+// calls of preprocess_backward_kernel, so a single view reproduces its dL/dsh bit for bit).
+__device__ inline void sh_basis(int deg, float x, float y, float z, float* Y) {
+    Y[0] = kC0;
+    if (deg > 0) {
+        Y[1] = -kC1 * y; Y[2] = kC1 * z; Y[3] = -kC1 * x;
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            Y[4] = kC2[0] * xy; Y[5] = kC2[1] * yz; Y[6] = kC2[2] * (2.f * zz - xx - yy);
+            Y[7] = kC2[3] * xz; Y[8] = kC2[4] * (xx - yy);
+            if (deg > 2) {
+                Y[9] = kC3[0] * y * (3.f * xx - yy); Y[10] = kC3[1] * xy * z;
+                Y[11] = kC3[2] * y * (4.f * zz - xx - yy); Y[12] = kC3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                Y[13] = kC3[4] * x * (4.f * zz - xx - yy); Y[14] = kC3[5] * z * (xx - yy);
+                Y[15] = kC3[6] * x * (xx - 3.f * yy);
+            }
+        }
+    }
+}
+
+// dL_dsh[p,m,c] = sum_v Y_m(dir_v(p)) * dL_drgb[v,p,c]: one thread per Gaussian, views in order (deterministic).
+// HBM: reads 12 B (mean) + V * 12 B, writes 12 * M B per Gaussian.
+__global__ __launch_bounds__(kBlock) void sh_grad_from_views_kernel(
+    int P, int V, int sh_degree, int sh_coeffs, const float* __restrict__ means3D, const float* __restrict__ campos,
+    const float* __restrict__ dL_drgb, float* __restrict__ dL_dsh) {
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= P) return;
+    const float x = means3D[3 * idx], y = means3D[3 * idx + 1], z = means3D[3 * idx + 2];
+    const int used = (sh_degree + 1) * (sh_degree + 1);
+    float acc[48];
+#pragma unroll
+    for (int k = 0; k < 48; ++k) acc[k] = 0.f;
+    for (int v = 0; v < V; ++v) {
+        const float* g = dL_drgb + ((size_t)v * P + idx) * 3;
+        const float g0 = g[0], g1 = g[1], g2 = g[2];
+        if (g0 == 0.f && g1 == 0.f && g2 == 0.f) continue;      // culled / clamped in this view: adds exact zeros
+        const float ox = x - campos[3 * v], oy = y - campos[3 * v + 1], oz = z - campos[3 * v + 2];
+        const float il = rsqrtf(ox * ox + oy * oy + oz * oz);
+        float Y[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) Y[k] = 0.f;
+        sh_basis(sh_degree, ox * il, oy * il, oz * il, Y);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            // separate multiply and add (no FMA): for V == 1 this equals preprocess_backward_kernel's store exactly
+            acc[3 * k] = __fadd_rn(acc[3 * k], __fmul_rn(Y[k], g0));
+            acc[3 * k + 1] = __fadd_rn(acc[3 * k + 1], __fmul_rn(Y[k], g1));
+            acc[3 * k + 2] = __fadd_rn(acc[3 * k + 2], __fmul_rn(Y[k], g2));
+        }
+    }
+    float* dsh = dL_dsh + (size_t)idx * sh_coeffs * 3;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        if (k < sh_coeffs) {
+            const bool on = k < used;
+            dsh[3 * k] = on ? acc[3 * k] : 0.f; dsh[3 * k + 1] = on ? acc[3 * k + 1] : 0.f;
+            dsh[3 * k + 2] = on ? acc[3 * k + 2] : 0.f;
+        }
+    }
+    for (int k = 16; k < sh_coeffs; ++k) { dsh[3 * k] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f; }
+}
+
 }  // namespace
+
+int launch_sh_grad_from_views(int P, int V, int sh_degree, int sh_coeffs, const float* means3D, const float* campos,
+                              const float* dL_drgb, float* dL_dsh, hipStream_t s) {
+    if (P <= 0) return OGS_OK;
+    OGS_LAUNCH(sh_grad_from_views_kernel, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, P, V, sh_degree, sh_coeffs,
+               means3D, campos, dL_drgb, dL_dsh);
+    return OGS_OK;
+}
 
 int launch_preprocess_backward(const OgsRasterBwdArgs& a, const GeomState& gs, const float* grad_rec, hipStream_t s) {
     if (a.P <= 0) return OGS_OK;

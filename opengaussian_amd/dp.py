@@ -90,6 +90,71 @@ class GradBucket:
         return self.views()
 
 
+class ShGradExchange:
+    """Exact low-traffic replacement for all-reducing the dense SH gradient.
+
+    For one view dL/dsh[p,m,c] = Y_m(dir(p)) * dL/dRGB[p,c] (rank 1), and every rank knows every view's camera
+    centre, so the ranks all-gather the [P,3] factor (rasterizer `sh_rgb_sink`) and each rebuilds
+    sum_v Y_m(dir_v(p)) * dL/dRGB_v[p,c] locally with ogs_sh_grad_from_views.  At degree 3 that puts 3*(N-1)
+    floats per Gaussian on each GPU's xGMI links instead of the ~2*48*(N-1)/N of a ring all-reduce (21 vs 84 at
+    N = 8), and the summation order over views is fixed, so the result does not depend on the collective's
+    algorithm."""
+
+    def __init__(self, P: int, sh_coeffs: int, device, group=None):
+        self.P, self.M = int(P), int(sh_coeffs)
+        self.group = group
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self.gathered = torch.zeros(self.world, self.P, 3, dtype=torch.float32, device=device)
+        self._work = None
+        self._stream = torch.cuda.Stream(device) if torch.device(device).type == "cuda" else None
+
+    def gather_async(self, dL_drgb: torch.Tensor):
+        """Start the all-gather of this rank's [P,3] factor on a side stream."""
+        if self.world == 1:
+            self.gathered[0].copy_(dL_drgb)
+            return
+        local = self.gathered[self.rank]
+        local.copy_(dL_drgb)
+
+        def issue():
+            return dist.all_gather_into_tensor(self.gathered.view(-1), local.view(-1), group=self.group, async_op=True)
+        if self._stream is not None:
+            self._stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._stream):
+                self._work = issue()
+        else:
+            self._work = issue()
+
+    def wait(self) -> torch.Tensor:
+        """[V,P,3] factors of all views (view v = rank v), ready on the current stream."""
+        if self._work is not None:
+            self._work.wait()
+            if self._stream is not None:
+                torch.cuda.current_stream().wait_stream(self._stream)
+            self._work = None
+        return self.gathered
+
+    def rebuild(self, means3D: torch.Tensor, campos_all: torch.Tensor, sh_degree: int,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """sum over views of dL/dsh, [P,M,3] (HIP kernel; GPU only).  campos_all: [V,3] camera centres, row v =
+        the view rank v rendered."""
+        from . import _lib
+        g = self.wait()
+        if not g.is_cuda:
+            raise RuntimeError("ShGradExchange.rebuild needs the HIP library (GPU tensors)")
+        if out is None:
+            out = torch.empty(self.P, self.M, 3, dtype=torch.float32, device=g.device)
+        m3 = means3D.detach().to(torch.float32).contiguous()
+        cp = campos_all.detach().to(device=g.device, dtype=torch.float32).contiguous()
+        if cp.shape != (self.world, 3):
+            raise RuntimeError(f"campos_all must be [{self.world},3]")
+        _lib.check(_lib.lib().ogs_sh_grad_from_views(self.P, self.world, int(sh_degree), self.M, m3.data_ptr(),
+                                                     cp.data_ptr(), g.data_ptr(), out.data_ptr(),
+                                                     torch.cuda.current_stream().cuda_stream), "ogs_sh_grad_from_views")
+        return out
+
+
 def densification_stats(grad_means2D: torch.Tensor, radii: torch.Tensor) -> torch.Tensor:
     """This view's [2, P] SUM-reducible statistics: row 0 = ||grad_means2D[:, :2]|| on visible Gaussians, row 1 =
     visibility (0/1).  Append it to the gradient bucket so that it rides in the same all-reduce; MAX(radii) still

@@ -62,9 +62,10 @@ def _require_gpu(t: torch.Tensor, name: str):
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings: GaussianRasterizationSettings, geom_channels: int = 0):
+                raster_settings: GaussianRasterizationSettings, geom_channels: int = 0, sh_rgb_sink=None):
         rs = raster_settings
         ctx.geom_channels = int(geom_channels)
+        ctx.sh_rgb_sink = sh_rgb_sink
         _require_gpu(means3D, "means3D")
         dev = means3D.device
         lib = _lib.lib()
@@ -178,7 +179,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         P, Cn = ctx.P, ctx.Cn
         if P == 0:
-            return (None,) * 10
+            return (None,) * 11
         (m3, shs, cols, opac, scl, rot, cov, bg, view, proj, campos, radii, alpha, geom, image,
          point_list, sorted_rec) = ctx.saved_tensors
         dev = m3.device
@@ -189,7 +190,10 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         g_m3 = z(P, 3) if need[0] else None
         g_m2 = z(P, 3) if need[1] else None
-        g_sh = z(*shs.shape) if (need[2] and shs is not None) else None
+        # data-parallel mode (dp.ShGradExchange): hand out the rank-1 factor [P,3] instead of the dense dL/dsh
+        sink = ctx.sh_rgb_sink if (need[2] and shs is not None) else None
+        g_sh = z(*shs.shape) if (need[2] and shs is not None and sink is None) else None
+        g_sh_rgb = z(P, 3) if sink is not None else None
         g_col = z(*cols.shape) if (need[3] and cols is not None) else None
         g_op = z(P, 1) if need[4] else None
         g_scl = z(P, 3) if (need[5] and scl is not None) else None
@@ -220,18 +224,24 @@ class _RasterizeGaussians(torch.autograd.Function):
         b.geom_buffer, b.image_buffer, b.point_list, b.bwd_tmp = ptr(geom), ptr(image), ptr(point_list), ptr(bwd_tmp)
         b.dL_dmeans2D, b.dL_dcolors, b.dL_dopacity, b.dL_dmeans3D = ptr(g_m2), ptr(g_col), ptr(g_op), ptr(g_m3)
         b.dL_dcov3D, b.dL_dsh, b.dL_dscales, b.dL_drotations = ptr(g_cov), ptr(g_sh), ptr(g_scl), ptr(g_rot)
+        b.dL_dsh_rgb = ptr(g_sh_rgb)
         check(lib.ogs_raster_backward(C.byref(b), _stream()), "ogs_raster_backward")
-        return g_m3, g_m2, g_sh, g_col, g_op, g_scl, g_rot, g_cov, None, None
+        if sink is not None:
+            sink.append(g_sh_rgb)
+        return g_m3, g_m2, g_sh, g_col, g_op, g_scl, g_rot, g_cov, None, None, None
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings):
+                        raster_settings, sh_rgb_sink=None):
+    """sh_rgb_sink (extension, data parallelism): a list.  When given, backward does NOT produce the dense
+    dL/dsh (shs.grad stays None); it appends the [P,3] clamp-masked gradient of the SH-evaluated RGB instead, from
+    which dp.ShGradExchange rebuilds the sum over views of dL/dsh (see include/ogs_raster.h, dL_dsh_rgb)."""
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings, 0)
+                                     cov3Ds_precomp, raster_settings, 0, sh_rgb_sink)
 
 
 def rasterize_fused(means3D, means2D, opacities, shs, extra_feats, raster_settings, scales=None, rotations=None,
-                    cov3D_precomp=None, detach_extra_from_geometry=True):
+                    cov3D_precomp=None, detach_extra_from_geometry=True, sh_rgb_sink=None):
     """ONE pass for what the reference renders in several (gaussian_renderer/__init__.py:104-163): RGB from SH in
     channels 0..2 plus `extra_feats` [P, 3|6|9] (e.g. the 6-D ins_feat) in the following channels -- one
     preprocess / sort / blend for all of them.  Returns (color [3+E,H,W], radii, depth, alpha).
@@ -244,7 +254,7 @@ def rasterize_fused(means3D, means2D, opacities, shs, extra_feats, raster_settin
     return _RasterizeGaussians.apply(means3D, means2D, shs, extra_feats, opacities,
                                      empty if scales is None else scales, empty if rotations is None else rotations,
                                      empty if cov3D_precomp is None else cov3D_precomp, raster_settings,
-                                     3 if detach_extra_from_geometry else 0)
+                                     3 if detach_extra_from_geometry else 0, sh_rgb_sink)
 
 
 class GaussianRasterizer(nn.Module):

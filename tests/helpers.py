@@ -89,3 +89,18 @@ def hip_export_binning(color_tensor):
     torch.cuda.synchronize()
     return (keys[:D].cpu().numpy().view(np.uint64), ranges.cpu().numpy().view(np.uint32),
             ncontrib.cpu().numpy().view(np.uint32), point_list[:D].cpu().numpy().view(np.uint32))
+
+
+def assert_close_modulo_threshold_flips(got, want, tol=1e-4, flip_tol=4e-3, max_pixels=2):
+    """Image comparison at `tol`, allowing a bounded number of PIXELS to differ by one blending contribution.
+
+    The reference skips a contribution when alpha < 1/255 and stops at T < 1e-4.  The
+    device exp and the host exp differ in the last ulp, so for a pixel whose alpha lands within 1 ulp of 1/255 one
+    contribution of size <= alpha * T * c ~ 4e-3 appears or disappears (scripts/diag_flip.py prints the offending
+    alpha * 255 = 0.99999994 for the case that motivated this helper).  At most max(max_pixels, 1e-5 * pixels)
+    pixels may do that, and none may be off by more than flip_tol."""
+    got, want = np.asarray(got), np.asarray(want)
+    diff = np.abs(got - want).reshape(-1, got.shape[-2], got.shape[-1]).max(0)
+    assert diff.max() < flip_tol, f"max difference {diff.max()}"
+    nbad = int((diff > tol).sum())
+    assert nbad <= max(max_pixels, 1e-5 * diff.size), f"{nbad} pixels off by more than {tol} (max {diff.max()})"

@@ -94,3 +94,39 @@ def test_shard_views():
     assert dp.shard_views(8, 3, 8) == [3]
     assert dp.shard_views(8, 1, 2) == [1, 3, 5, 7]
     assert sorted(sum((dp.shard_views(5, r, 4) for r in range(4)), [])) == list(range(5))
+
+
+def _gather_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dp.init_from_env("cpu")
+    P = 23
+    ex = dp.ShGradExchange(P, 16, "cpu")
+    mine = torch.arange(P * 3, dtype=torch.float32).view(P, 3) * (rank + 1)
+    ex.gather_async(mine)
+    g = ex.wait()
+    ok = g.shape == (world, P, 3) and all(torch.equal(g[r], torch.arange(P * 3, dtype=torch.float32).view(P, 3) * (r + 1))
+                                          for r in range(world))
+    try:                                    # the rebuild is a HIP kernel: it must refuse CPU tensors, not fall back
+        ex.rebuild(torch.zeros(P, 3), torch.zeros(world, 3), 3)
+        ok = False
+    except RuntimeError:
+        pass
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sh_factor_all_gather_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]

@@ -1,0 +1,164 @@
+"""GPU tests of the data-parallel exchange: the rank-1 SH-gradient exchange
+(dp.ShGradExchange + ogs_sh_grad_from_views) must give what summing the dense per-view dL/dsh gives, and a
+two-rank run (gloo, both ranks on the one GPU of the test box) must reproduce a single-process sum over views."""
+import math
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def _view_settings(W, H, f, view, nviews, device):
+    from opengaussian_amd.rasterizer import GaussianRasterizationSettings
+    from opengaussian_amd.synthetic import orbit_camera
+    cam = orbit_camera(W, H, f, f, view_index=view, num_views=nviews).to(device)
+    return GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
+        bg=torch.zeros(3, device=device), scale_modifier=1.0, viewmatrix=cam.world_view_transform,
+        projmatrix=cam.full_proj_transform, sh_degree=3, campos=cam.camera_center, prefiltered=False, debug=False), cam
+
+
+def _one_view(scene, settings, gC, gF, sink):
+    from opengaussian_amd.rasterizer import rasterize_fused
+    leaves = dict(means3D=scene.means3D, scales=scene.scales, rotations=scene.rotations, opacities=scene.opacities,
+                  shs=scene.shs, ins_feat=scene.ins_feat)
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in leaves.items()}
+    m2 = torch.zeros(scene.means3D.shape[0], 3, device=scene.means3D.device, requires_grad=True)
+    color, radii, depth, alpha = rasterize_fused(leaves["means3D"], m2, leaves["opacities"], leaves["shs"],
+                                                 leaves["ins_feat"], settings, scales=leaves["scales"],
+                                                 rotations=leaves["rotations"], sh_rgb_sink=sink)
+    torch.autograd.backward([color], [torch.cat([gC, gF])])
+    return leaves, radii
+
+
+@pytest.mark.parametrize("nviews", [1, 3])
+def test_sh_gradient_from_rank1_factors_equals_dense_sum(gpu_device, nviews):
+    from opengaussian_amd import dp
+    from opengaussian_amd.synthetic import make_scene
+    P, W, H, f = 6000, 160, 96, 120.0
+    scene = make_scene(P, W, H, f, f, seed=11).to(gpu_device)
+    g = torch.Generator().manual_seed(5)
+    gC = torch.randn(3, H, W, generator=g).to(gpu_device)
+    gF = torch.randn(6, H, W, generator=g).to(gpu_device)
+    dense_sum = torch.zeros(P, 16, 3, device=gpu_device, dtype=torch.float64)
+    factors, campos, others = [], [], []
+    for v in range(nviews):
+        st, cam = _view_settings(W, H, f, v, nviews, gpu_device)
+        dense, _ = _one_view(scene, st, gC, gF, None)
+        sink = []
+        comp, _ = _one_view(scene, st, gC, gF, sink)
+        assert comp["shs"].grad is None and len(sink) == 1 and sink[0].shape == (P, 3)
+        for k in ("means3D", "scales", "rotations", "opacities", "ins_feat"):
+            # atomics order differs run to run: equal up to fp32 summation noise
+            torch.testing.assert_close(comp[k].grad, dense[k].grad, rtol=1e-4, atol=1e-5 * float(dense[k].grad.abs().max()))
+        dense_sum += dense["shs"].grad.double()
+        factors.append(sink[0]); campos.append(cam.camera_center)
+        others.append(dense["shs"].grad)
+    ex = dp.ShGradExchange(P, 16, gpu_device)
+    assert ex.world == 1
+    if nviews == 1:
+        ex.gather_async(factors[0])
+        out = ex.rebuild(scene.means3D, torch.stack(campos), 3)
+        # one view: same basis polynomials, same multiply -> the dense gradient up to the atomics noise of the
+        # two separate backward runs feeding it
+        torch.testing.assert_close(out, others[0], rtol=1e-4, atol=1e-5 * float(others[0].abs().max()))
+        # and exactly rank 1: dsh[:, 0, :] == C0 * factor
+        torch.testing.assert_close(out[:, 0, :], 0.28209479177387814 * factors[0], rtol=1e-6, atol=0)
+    else:
+        ex.world = nviews                       # single process standing in for V ranks: fill the gathered buffer
+        ex.gathered = torch.stack(factors)
+        out = ex.rebuild(scene.means3D, torch.stack(campos), 3)
+        scale = float(dense_sum.abs().max())
+        assert float((out.double() - dense_sum).abs().max()) / scale < 2e-5
+        assert float(out.abs().sum()) > 0
+
+
+def test_sh_gradient_unused_coefficients_are_zero(gpu_device):
+    from opengaussian_amd import _lib
+    P = 1000
+    g = torch.Generator().manual_seed(0)
+    m3 = torch.randn(P, 3, generator=g).to(gpu_device)
+    fac = torch.randn(2, P, 3, generator=g).to(gpu_device)
+    cp = torch.tensor([[0.0, 0.0, -5.0], [4.0, 0.0, 3.0]], device=gpu_device)
+    out = torch.full((P, 16, 3), float("nan"), device=gpu_device)
+    _lib.check(_lib.lib().ogs_sh_grad_from_views(P, 2, 1, 16, m3.data_ptr(), cp.data_ptr(), fac.data_ptr(),
+                                                 out.data_ptr(), torch.cuda.current_stream().cuda_stream), "sh")
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all() and float(out[:, 4:].abs().max()) == 0.0 and float(out[:, :4].abs().min()) >= 0
+    d = m3[None] - cp[:, None]
+    d = d / d.norm(dim=-1, keepdim=True)
+    want1 = (-0.4886025119029199 * d[..., 1:2] * fac).sum(0)       # Y_1 = -C1 * y
+    torch.testing.assert_close(out[:, 1, :], want1, rtol=1e-4, atol=1e-5)
+    # invalid arguments are refused, not launched
+    assert _lib.lib().ogs_sh_grad_from_views(P, 0, 1, 16, m3.data_ptr(), cp.data_ptr(), fac.data_ptr(), out.data_ptr(), 0) != 0
+    assert _lib.lib().ogs_sh_grad_from_views(P, 2, 3, 9, m3.data_ptr(), cp.data_ptr(), fac.data_ptr(), out.data_ptr(), 0) != 0
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_main(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), OGS_DIST_BACKEND="gloo")
+    import torch.distributed as dist
+    from opengaussian_amd import dp
+    from opengaussian_amd.synthetic import make_scene
+    dp.init_from_env("cuda")
+    dev = torch.device("cuda", 0)
+    P, W, H, f = 4000, 128, 80, 100.0
+    scene = make_scene(P, W, H, f, f, seed=3).to(dev)
+    g = torch.Generator().manual_seed(9)
+    gC = torch.randn(3, H, W, generator=g).to(dev)
+    gF = torch.randn(6, H, W, generator=g).to(dev)
+    st, cam = _view_settings(W, H, f, rank, world, dev)
+    sink = []
+    leaves, radii = _one_view(scene, st, gC, gF, sink)
+    names = ["means3D", "scales", "rotations", "opacities", "ins_feat"]
+    bucket = dp.GradBucket([leaves[n].shape for n in names], dev, average=False)
+    bucket.pack([leaves[n].grad for n in names])
+    bucket.allreduce_async()
+    ex = dp.ShGradExchange(P, 16, dev)
+    ex.gather_async(sink[0])
+    campos_all = torch.stack([_view_settings(W, H, f, r, world, dev)[1].camera_center for r in range(world)])
+    dsh = ex.rebuild(scene.means3D, campos_all, 3)
+    red = bucket.wait()
+    # single-process truth: every view rendered here, dense gradients summed in float64
+    want = {n: torch.zeros_like(leaves[n], dtype=torch.float64) for n in names + ["shs"]}
+    for r in range(world):
+        lv, _ = _one_view(scene, _view_settings(W, H, f, r, world, dev)[0], gC, gF, None)
+        for n in want:
+            want[n] += lv[n].grad.double()
+    err = {n: float((t.double() - want[n]).abs().max() / (want[n].abs().max() + 1e-30)) for n, t in zip(names, red)}
+    err["shs"] = float((dsh.double() - want["shs"]).abs().max() / want["shs"].abs().max())
+    q.put((rank, err))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_exchange_matches_single_process_sum(gpu_device):
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err in res:
+        for k, e in err.items():
+            assert e < 1e-4, (rank, k, e)
