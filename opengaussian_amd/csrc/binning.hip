@@ -70,6 +70,11 @@ __global__ __launch_bounds__(kBlock) void scan_reduce_kernel(const uint32_t* __r
 }
 
 // partial_offsets == nullptr: single-workgroup scan.  total_out (optional) gets the grand total.
+// SUM_PARTIALS: partial_offsets holds the per-workgroup SUMS (scan_reduce_kernel's output, not yet scanned) and
+// every workgroup adds up the ones before it itself -- for a few thousand workgroups that is cheaper than the
+// extra launches of a second scan level (each is ~5 us of dependent launch latency); the last workgroup then
+// also knows the grand total.
+template <bool SUM_PARTIALS>
 __global__ __launch_bounds__(kBlock) void scan_apply_kernel(const uint32_t* __restrict__ in,
                                                             const uint32_t* __restrict__ gather,
                                                             uint32_t* __restrict__ out, int64_t n,
@@ -82,16 +87,28 @@ __global__ __launch_bounds__(kBlock) void scan_apply_kernel(const uint32_t* __re
     uint32_t s = 0;
 #pragma unroll
     for (int i = 0; i < kScanItems; ++i) s += item[i];
+    uint32_t block_base = 0;
+    if (SUM_PARTIALS) {
+        uint32_t acc = 0;
+        for (uint32_t j = threadIdx.x; j < blockIdx.x; j += kBlock) acc += partial_offsets[j];
+        uint32_t tot;
+        block_exclusive_scan(acc, tot, wave_sums);
+        block_base = tot;
+    } else if (partial_offsets) {
+        block_base = partial_offsets[blockIdx.x];
+    }
     uint32_t total;
-    uint32_t run = block_exclusive_scan(s, total, wave_sums);
-    if (partial_offsets) run += partial_offsets[blockIdx.x];
+    uint32_t run = block_exclusive_scan(s, total, wave_sums) + block_base;
 #pragma unroll
     for (int i = 0; i < kScanItems; ++i) {
         const int64_t idx = base + i;
         if (idx < n) out[idx] = run;
         run += item[i];
     }
-    if (total_out && partial_offsets == nullptr && threadIdx.x == 0) *total_out = total;
+    if (total_out && threadIdx.x == 0) {
+        if (SUM_PARTIALS) { if (blockIdx.x == gridDim.x - 1) *total_out = block_base + total; }
+        else if (partial_offsets == nullptr) *total_out = total;
+    }
 }
 
 // grand total for the multi-level case: offset of the last block + its sum = exclusive[n-1] + in[n-1]
@@ -104,6 +121,7 @@ __global__ void scan_total_kernel(const uint32_t* __restrict__ in, const uint32_
 }
 
 inline int scan_blocks(int64_t n) { return (int)((n + kScanTile - 1) / kScanTile); }
+constexpr int kFlatScanBlocks = 16384;   // up to 33.5 M elements scan in two launches
 
 // ---- radix pass -----------------------------------------------------------------------------------
 // n_dev (optional): the element count lives in device memory (deferred render phase: the host sized the launch
@@ -127,14 +145,47 @@ __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const uint32_t* __re
     if ((int)threadIdx.x < ndig) hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
+// In-place exclusive scan of every digit row hist[d][0..nblocks) (one workgroup per digit) + the row totals.
+// The scatter kernel adds the exclusive prefix over the row totals itself (<= 256 values), which replaces the
+// 3-launch global scan of the ndig*nblocks table by this single launch.
+__global__ __launch_bounds__(kBlock) void radix_rowscan_kernel(uint32_t* __restrict__ hist, int nblocks,
+                                                               uint32_t* __restrict__ row_total) {
+    __shared__ uint32_t wave_sums[4];
+    uint32_t* row = hist + (size_t)blockIdx.x * nblocks;
+    uint32_t carry = 0;
+    for (int base = 0; base < nblocks; base += kScanTile) {
+        uint32_t item[kScanItems];
+        // thread t owns items t, t+256, ... of this chunk?  No: consecutive items per thread keep the scan a
+        // simple (thread-sum, block-scan, thread-walk); rows are a few KB and stay in L2, so coalescing is moot.
+        const int b0 = base + (int)threadIdx.x * kScanItems;
+        uint32_t sum = 0;
+#pragma unroll
+        for (int i = 0; i < kScanItems; ++i) {
+            item[i] = (b0 + i < nblocks) ? row[b0 + i] : 0u;
+            sum += item[i];
+        }
+        uint32_t total;
+        uint32_t run = carry + block_exclusive_scan(sum, total, wave_sums);
+#pragma unroll
+        for (int i = 0; i < kScanItems; ++i) {
+            if (b0 + i < nblocks) row[b0 + i] = run;
+            run += item[i];
+        }
+        carry += total;
+    }
+    if (threadIdx.x == 0) row_total[blockIdx.x] = carry;
+}
+
 __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                                const uint32_t* __restrict__ vals_in,
                                                                uint32_t* __restrict__ keys_out,
                                                                uint32_t* __restrict__ vals_out, int64_t n_cap,
                                                                const uint32_t* __restrict__ n_dev, int shift,
                                                                int bits, const uint32_t* __restrict__ offsets,
+                                                               const uint32_t* __restrict__ row_total,
                                                                int nblocks) {
     __shared__ uint32_t wave_hist_s[kBlock / kWave][256];
+    __shared__ uint32_t scan_sums[4];
     volatile uint32_t(*wave_hist)[256] = wave_hist_s;
     const int64_t n = n_dev ? min((int64_t)*n_dev, n_cap) : n_cap;
     const int ndig = 1 << bits;
@@ -177,8 +228,11 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint32_t* _
         rank[i] = pre + r;
     }
     __syncthreads();
+    // global start of digit `tid` = sum of the totals of all smaller digits (exclusive scan over <= 256 values)
+    uint32_t dummy_total;
+    const uint32_t digit_base = block_exclusive_scan(tid < ndig ? row_total[tid] : 0u, dummy_total, scan_sums);
     if (tid < ndig) {
-        uint32_t run = offsets[(size_t)tid * nblocks + blockIdx.x];
+        uint32_t run = digit_base + offsets[(size_t)tid * nblocks + blockIdx.x];
 #pragma unroll
         for (int w = 0; w < kBlock / kWave; ++w) {
             const uint32_t t = wave_hist_s[w][tid];
@@ -247,7 +301,8 @@ size_t scan_tmp_bytes(int64_t n) {
 
 size_t sort_tmp_bytes(int64_t n) {
     const int64_t hist = (int64_t)256 * sort_blocks(n > 0 ? n : 1);
-    return align_up((size_t)hist * sizeof(uint32_t)) + scan_tmp_bytes(hist);
+    // histogram table + 256 row totals; the tail is also what exclusive_scan_u32 callers borrow as scan scratch
+    return align_up((size_t)hist * sizeof(uint32_t)) + align_up(256 * sizeof(uint32_t)) + scan_tmp_bytes(hist);
 }
 
 int exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int64_t n, uint32_t* total,
@@ -258,7 +313,7 @@ int exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out
     }
     const int nb = scan_blocks(n);
     if (nb == 1) {
-        OGS_LAUNCH(scan_apply_kernel, dim3(1), dim3(kBlock), 0, stream, in, gather, out, n,
+        OGS_LAUNCH(scan_apply_kernel<false>, dim3(1), dim3(kBlock), 0, stream, in, gather, out, n,
                            (const uint32_t*)nullptr, total);
         OGS_LAUNCH_CHECK(debug, stream);
         return OGS_OK;
@@ -267,9 +322,16 @@ int exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out
     void* next_tmp = static_cast<char*>(tmp) + align_up((size_t)nb * sizeof(uint32_t));
     OGS_LAUNCH(scan_reduce_kernel, dim3(nb), dim3(kBlock), 0, stream, in, gather, n, partials);
     OGS_LAUNCH_CHECK(debug, stream);
+    if (nb <= kFlatScanBlocks) {
+        // two launches: every workgroup sums the partials before it (<= 16 K values, L2 resident)
+        OGS_LAUNCH(scan_apply_kernel<true>, dim3(nb), dim3(kBlock), 0, stream, in, gather, out, n,
+                           (const uint32_t*)partials, total);
+        OGS_LAUNCH_CHECK(debug, stream);
+        return OGS_OK;
+    }
     int rc = exclusive_scan_u32(partials, nullptr, partials, nb, nullptr, next_tmp, stream, debug);
     if (rc != OGS_OK) return rc;
-    OGS_LAUNCH(scan_apply_kernel, dim3(nb), dim3(kBlock), 0, stream, in, gather, out, n,
+    OGS_LAUNCH(scan_apply_kernel<false>, dim3(nb), dim3(kBlock), 0, stream, in, gather, out, n,
                        (const uint32_t*)partials, (uint32_t*)nullptr);
     OGS_LAUNCH_CHECK(debug, stream);
     if (total) {
@@ -289,13 +351,13 @@ int radix_pass(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_
     const int nb = sort_blocks(n);
     const int ndig = 1 << bits;
     uint32_t* hist = static_cast<uint32_t*>(tmp);
-    void* scan_tmp = static_cast<char*>(tmp) + align_up((size_t)256 * nb * sizeof(uint32_t));
+    uint32_t* row_total = reinterpret_cast<uint32_t*>(static_cast<char*>(tmp) + align_up((size_t)256 * nb * sizeof(uint32_t)));
     OGS_LAUNCH(radix_hist_kernel, dim3(nb), dim3(kBlock), 0, stream, keys_in, n, n_dev, shift, bits, hist, nb);
     OGS_LAUNCH_CHECK(debug, stream);
-    int rc = exclusive_scan_u32(hist, nullptr, hist, (int64_t)ndig * nb, nullptr, scan_tmp, stream, debug);
-    if (rc != OGS_OK) return rc;
+    OGS_LAUNCH(radix_rowscan_kernel, dim3(ndig), dim3(kBlock), 0, stream, hist, nb, row_total);
+    OGS_LAUNCH_CHECK(debug, stream);
     OGS_LAUNCH(radix_scatter_kernel, dim3(nb), dim3(kBlock), 0, stream, keys_in, vals_in, keys_out, vals_out, n, n_dev,
-                       shift, bits, (const uint32_t*)hist, nb);
+                       shift, bits, (const uint32_t*)hist, (const uint32_t*)row_total, nb);
     OGS_LAUNCH_CHECK(debug, stream);
     return OGS_OK;
 }

@@ -249,32 +249,85 @@ __global__ __launch_bounds__(kBlock) void duplicate_kernel(int P, int W, int H, 
                                                            uint32_t* __restrict__ vals, uint32_t capacity) {
     // capacity: size of tile_keys / vals.  In the deferred render phase it is a cached estimate and the true
     // num_rendered may exceed it: such entries are dropped here and the host re-runs the phase (rasterizer.py).
-    const int r = blockIdx.x * kBlock + threadIdx.x;
-    if (r >= P) return;
-    const uint32_t gid = order[r];
-    const float4 a = rec[(size_t)gid * NV];
-    const int radius = __float_as_int(a.w);
-    if (radius <= 0) return;
+    //
+    // Load-balanced expansion: the 256 Gaussians of a workgroup own one CONTIGUOUS output range (their offsets
+    // are an exclusive scan in this very order), so the workgroup walks that range with one output slot per
+    // thread -- perfectly coalesced 4-byte stores -- and finds the owning Gaussian of a slot by binary search in
+    // LDS.  (One thread per Gaussian looping over its own tiles wrote 64 scattered dwords per store instruction
+    // and ran as long as the wave's largest footprint: 121 us instead of ~35 us at S1M-1080p.)
+    __shared__ uint32_t s_off[kBlock];      // output offset relative to the workgroup's first slot
+    __shared__ uint32_t s_gid[kBlock];
+    __shared__ uint32_t s_rect[kBlock];     // rminx | rminy << 12 | width << 24   (grids up to 4095 tiles a side)
+    __shared__ uint32_t s_first, s_total;
+    const int tid = threadIdx.x;
+    const int r = blockIdx.x * kBlock + tid;
     const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
-    const float rf = (float)radius;
-    auto tr = [](float v) -> int {
-        if (!(fabsf(v) < 3.0e38f)) v = 0.f;
-        v = fminf(fmaxf(v, -2.0e9f), 2.0e9f);
-        return (int)v;
-    };
-    const int rminx = min(gx, max(0, tr((a.x - rf) / (float)kTile)));
-    const int rminy = min(gy, max(0, tr((a.y - rf) / (float)kTile)));
-    const int rmaxx = min(gx, max(0, tr((a.x + rf + (float)kTile - 1.0f) / (float)kTile)));
-    const int rmaxy = min(gy, max(0, tr((a.y + rf + (float)kTile - 1.0f) / (float)kTile)));
-    uint32_t off = offsets[r];
-    for (int ty = rminy; ty < rmaxy; ++ty)
-        for (int tx = rminx; tx < rmaxx; ++tx) {
-            if (off < capacity) {
-                tile_keys[off] = (uint32_t)(ty * gx + tx);
-                vals[off] = gid;
+    uint32_t off = 0, cnt = 0, gid = 0, rect = 1u << 24;
+    if (r < P) {
+        gid = order[r];
+        off = offsets[r];
+        const float4 a = rec[(size_t)gid * NV];
+        const int radius = __float_as_int(a.w);
+        if (radius > 0) {
+            const float rf = (float)radius;
+            auto tr = [](float v) -> int {
+                if (!(fabsf(v) < 3.0e38f)) v = 0.f;
+                v = fminf(fmaxf(v, -2.0e9f), 2.0e9f);
+                return (int)v;
+            };
+            const int rminx = min(gx, max(0, tr((a.x - rf) / (float)kTile)));
+            const int rminy = min(gy, max(0, tr((a.y - rf) / (float)kTile)));
+            const int rmaxx = min(gx, max(0, tr((a.x + rf + (float)kTile - 1.0f) / (float)kTile)));
+            const int rmaxy = min(gy, max(0, tr((a.y + rf + (float)kTile - 1.0f) / (float)kTile)));
+            const int w = rmaxx - rminx, h = rmaxy - rminy;
+            if (w > 0 && h > 0) {
+                cnt = (uint32_t)(w * h);
+                // width field is 8 bits: wider footprints (> 255 tiles = 4080 px) keep the per-thread loop below
+                rect = (uint32_t)rminx | ((uint32_t)rminy << 12) | ((uint32_t)min(w, 255) << 24);
+                if (w > 255) {
+                    uint32_t o = off;
+                    for (int ty = rminy; ty < rmaxy; ++ty)
+                        for (int tx = rminx; tx < rmaxx; ++tx) {
+                            if (o < capacity) { tile_keys[o] = (uint32_t)(ty * gx + tx); vals[o] = gid; }
+                            ++o;
+                        }
+                    rect |= 0u;            // slots of this Gaussian are skipped in the cooperative walk (marked below)
+                    gid |= 0x80000000u;    // P < 2^31: the top bit is free
+                }
             }
-            ++off;
         }
+    }
+    if (tid == 0) s_first = off;
+    __syncthreads();
+    const uint32_t first = s_first;
+    // Gaussians past P (last workgroup) sit at the end of the range with zero slots
+    s_off[tid] = (r < P) ? off - first : 0xFFFFFFFFu;
+    s_gid[tid] = gid;
+    s_rect[tid] = rect;
+    const int last = min(P - 1 - blockIdx.x * kBlock, kBlock - 1);
+    if (tid == last) s_total = off - first + cnt;
+    __syncthreads();
+    const uint32_t total = s_total;
+    for (uint32_t j = tid; j < total; j += kBlock) {
+        // owner = last i with s_off[i] <= j (zero-slot Gaussians share their offset with the next one)
+        int lo = 0, hi = kBlock;             // invariant: s_off[lo] <= j, answer in [lo, hi)
+#pragma unroll
+        for (int step = kBlock / 2; step >= 1; step >>= 1) {
+            const int mid = lo + step;
+            if (mid < hi && s_off[mid] <= j) lo = mid;
+        }
+        const uint32_t g = s_gid[lo];
+        if (g & 0x80000000u) continue;       // written by its own thread above
+        const uint32_t rc = s_rect[lo];
+        const uint32_t local = j - s_off[lo];
+        const uint32_t w = rc >> 24;
+        const uint32_t row = local / w, col = local - row * w;
+        const uint32_t o = first + j;
+        if (o < capacity) {
+            tile_keys[o] = ((rc >> 12 & 0xFFFu) + row) * (uint32_t)gx + (rc & 0xFFFu) + col;
+            vals[o] = g;
+        }
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void mark_visible_kernel(int P, const float* __restrict__ means3D,
@@ -316,6 +369,10 @@ int launch_preprocess(const OgsRasterFwdArgs& a, const GeomState& gs, const Geom
 int launch_duplicate(const OgsRasterFwdArgs& a, const GeomState& gs, const GeomTmp& gt, uint32_t* tile_keys,
                      uint32_t* vals, uint32_t capacity, hipStream_t s) {
     const int grid = (a.P + kBlock - 1) / kBlock;
+    if ((a.W + kTile - 1) / kTile > 4095 || (a.H + kTile - 1) / kTile > 4095) {
+        set_error("image %dx%d exceeds 4095 tiles per side", a.W, a.H);
+        return OGS_ERR_UNSUPPORTED;
+    }
     switch (rec_vec4(a.C)) {
         case 3: OGS_LAUNCH(duplicate_kernel<3>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals, capacity); break;
         case 4: OGS_LAUNCH(duplicate_kernel<4>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals, capacity); break;

@@ -99,10 +99,12 @@ class _RasterizeGaussians(torch.autograd.Function):
         proj = _f32c(rs.projmatrix.to(dev))
         campos = _f32c(rs.campos.to(dev))
 
-        color = torch.zeros(Cn, H, W, dtype=torch.float32, device=dev)
-        depth = torch.zeros(1, H, W, dtype=torch.float32, device=dev)
-        alpha = torch.zeros(1, H, W, dtype=torch.float32, device=dev)
-        radii = torch.zeros(P, dtype=torch.int32, device=dev)
+        # P > 0: the kernels write every pixel of every tile and every radius, so no fill pass is needed
+        alloc = torch.zeros if P == 0 else torch.empty
+        color = alloc(Cn, H, W, dtype=torch.float32, device=dev)
+        depth = alloc(1, H, W, dtype=torch.float32, device=dev)
+        alpha = alloc(1, H, W, dtype=torch.float32, device=dev)
+        radii = alloc(P, dtype=torch.int32, device=dev)
         ctx.raster_settings = rs
         ctx.P, ctx.Cn, ctx.num_rendered = P, Cn, 0
         if P == 0:
