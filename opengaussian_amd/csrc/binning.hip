@@ -186,6 +186,8 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint32_t* _
                                                                int nblocks) {
     __shared__ uint32_t wave_hist_s[kBlock / kWave][256];
     __shared__ uint32_t scan_sums[4];
+    __shared__ uint32_t dig_start[256], glob_base[256];
+    __shared__ uint32_t stage_k[kSortTile], stage_v[kSortTile];
     volatile uint32_t(*wave_hist)[256] = wave_hist_s;
     const int64_t n = n_dev ? min((int64_t)*n_dev, n_cap) : n_cap;
     const int ndig = 1 << bits;
@@ -228,17 +230,25 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint32_t* _
         rank[i] = pre + r;
     }
     __syncthreads();
-    // global start of digit `tid` = sum of the totals of all smaller digits (exclusive scan over <= 256 values)
-    uint32_t dummy_total;
-    const uint32_t digit_base = block_exclusive_scan(tid < ndig ? row_total[tid] : 0u, dummy_total, scan_sums);
+    // per digit: offset of each wave inside the workgroup's run of that digit, and the run length
+    uint32_t run_len = 0;
     if (tid < ndig) {
-        uint32_t run = digit_base + offsets[(size_t)tid * nblocks + blockIdx.x];
 #pragma unroll
         for (int w = 0; w < kBlock / kWave; ++w) {
             const uint32_t t = wave_hist_s[w][tid];
-            wave_hist_s[w][tid] = run;
-            run += t;
+            wave_hist_s[w][tid] = run_len;
+            run_len += t;
         }
+    }
+    // workgroup-local start of every digit run (the keys are staged in LDS in sorted order) ...
+    uint32_t n_valid;
+    const uint32_t local_start = block_exclusive_scan(run_len, n_valid, scan_sums);
+    // ... and its global start: sum of the totals of all smaller digits + this digit's prefix over workgroups
+    uint32_t dummy_total;
+    const uint32_t digit_base = block_exclusive_scan(tid < ndig ? row_total[tid] : 0u, dummy_total, scan_sums);
+    if (tid < ndig) {
+        dig_start[tid] = local_start;
+        glob_base[tid] = digit_base + offsets[(size_t)tid * nblocks + blockIdx.x] - local_start;
     }
     __syncthreads();
 #pragma unroll
@@ -246,10 +256,19 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint32_t* _
         const int64_t idx = base + i * kWave + lane;
         if (idx < n) {
             const uint32_t d = (key[i] >> shift) & mask;
-            const uint32_t pos = wave_hist_s[wave][d] + rank[i];
-            keys_out[pos] = key[i];
-            vals_out[pos] = val[i];
+            const uint32_t lp = dig_start[d] + wave_hist_s[wave][d] + rank[i];
+            stage_k[lp] = key[i];
+            stage_v[lp] = val[i];
         }
+    }
+    __syncthreads();
+    // write-out in sorted order: consecutive threads hit consecutive addresses inside a digit run (runs average
+    // kSortTile / ndig keys), instead of 64 unrelated dwords per store instruction
+    for (uint32_t j = tid; j < n_valid; j += kBlock) {
+        const uint32_t k = stage_k[j];
+        const uint32_t pos = glob_base[(k >> shift) & mask] + j;
+        keys_out[pos] = k;
+        vals_out[pos] = stage_v[j];
     }
 }
 

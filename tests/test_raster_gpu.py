@@ -285,13 +285,17 @@ def _adversarial_scene(kind, P, W, H, f, seed):
     elif kind == "offscreen_edges":     # centres outside the frustum whose footprint still reaches the border
         sc.means3D[:, 0] = torch.sign(torch.rand(P, generator=g) - 0.5) * sc.means3D[:, 2] * (W / (2 * f)) * 1.25
         sc.scales[:] = 0.15
+    elif kind == "wide_footprint":      # footprints wider than 255 tiles: the duplicate kernel's per-thread fallback
+        sc.scales[::7] = 40.0
+        sc.opacities[::7] = 0.02
     elif kind == "depth_ties":          # many exactly equal depths: order must fall back to the Gaussian index
         sc.means3D[:, 2] = torch.round(sc.means3D[:, 2])
     return sc, cam
 
 
 @pytest.mark.parametrize("kind,P,W,H", [("long_lists", 3000, 48, 32), ("faint_and_opaque", 2000, 128, 80),
-                                        ("offscreen_edges", 1500, 112, 64), ("depth_ties", 2500, 128, 96)])
+                                        ("offscreen_edges", 1500, 112, 64), ("depth_ties", 2500, 128, 96),
+                                        ("wide_footprint", 210, 4400, 32)])
 def test_adversarial_scenes_forward_and_backward(gpu_device, kind, P, W, H):
     from oracle import raster_oracle as ro
     f = 70.0
@@ -309,6 +313,8 @@ def test_adversarial_scenes_forward_and_backward(gpu_device, kind, P, W, H):
     helpers.assert_close_modulo_threshold_flips(alpha.detach().cpu().numpy(), ref["alpha"], IMG_TOL)
     if kind == "long_lists":
         assert int((ranges[:, 1] - ranges[:, 0]).max()) >= 0.9 * (radii > 0).sum().item()
+    if kind == "wide_footprint":
+        assert int((ranges[:, 1] > ranges[:, 0]).sum()) == ranges.shape[0] and int(radii.max()) > 255 * 16
     if kind == "depth_ties":
         d = ref["geom"].depth[plist]
         assert (np.diff(d) == 0).sum() > 100       # the tie-break path really is exercised
