@@ -24,6 +24,7 @@ namespace ogs {
 namespace {
 
 constexpr float kAlphaMin = 1.0f / 255.0f;
+typedef float v2f __attribute__((ext_vector_type(2)));   // register pair -> v_pk_*_f32 (two fp32 ops per VALU issue)
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float src) {
@@ -33,17 +34,26 @@ __device__ __forceinline__ float dpp_mov(float src) {
 // Fold 16 per-lane slots across the wave: on return lane L holds sum over all 64 lanes of slot (L>>2).
 __device__ __forceinline__ float wave_fold16(float v[16]) {
     const int lane = lane_id();
+    // the two adds of neighbouring slots are issued as one packed v_pk_add_f32
     float u[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[k]), __float_as_uint(v[k + 8]), false, false);
-        u[k] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    for (int j = 0; j < 4; ++j) {
+        auto ra = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2 * j]), __float_as_uint(v[2 * j + 8]), false, false);
+        auto rb = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2 * j + 1]), __float_as_uint(v[2 * j + 9]), false, false);
+        const v2f lo = {__uint_as_float(ra[0]), __uint_as_float(rb[0])};
+        const v2f hi = {__uint_as_float(ra[1]), __uint_as_float(rb[1])};
+        const v2f t = lo + hi;
+        u[2 * j] = t.x; u[2 * j + 1] = t.y;
     }
     float w[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(u[k]), __float_as_uint(u[k + 4]), false, false);
-        w[k] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    for (int j = 0; j < 2; ++j) {
+        auto ra = __builtin_amdgcn_permlane16_swap(__float_as_uint(u[2 * j]), __float_as_uint(u[2 * j + 4]), false, false);
+        auto rb = __builtin_amdgcn_permlane16_swap(__float_as_uint(u[2 * j + 1]), __float_as_uint(u[2 * j + 5]), false, false);
+        const v2f lo = {__uint_as_float(ra[0]), __uint_as_float(rb[0])};
+        const v2f hi = {__uint_as_float(ra[1]), __uint_as_float(rb[1])};
+        const v2f t = lo + hi;
+        w[2 * j] = t.x; w[2 * j + 1] = t.y;
     }
     const bool b3 = (lane & 8) != 0;
     float x[2];
@@ -109,11 +119,20 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     }
     const float gd = (inside && dL_ddepth) ? dL_ddepth[pix] : 0.f;
     const float ga = (inside && dL_dalpha_map) ? dL_dalpha_map[pix] : 0.f;
+    // (dL/dpixel_0 .. dL/dpixel_{C-1}, dL/ddepth) as register pairs for v_pk_mul_f32
+    constexpr int NP = (C + 2) / 2;
+    v2f gp[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        gp[k].x = 2 * k < C ? g[2 * k < C ? 2 * k : 0] : (2 * k == C ? gd : 0.f);
+        gp[k].y = 2 * k + 1 < C ? g[2 * k + 1 < C ? 2 * k + 1 : 0] : (2 * k + 1 == C ? gd : 0.f);
+    }
     float R[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) R[c] = 0.f;
     float Rd = 0.f, Ra = 0.f;
     const float halfW = 0.5f * (float)W, halfH = 0.5f * (float)H;
+    const float tf_bg = T_final * bg_dot;                  // loop invariant of the background term
 
     // Same SALU-frugal loop shape as blend_fwd.hip: no break / continue, two ping-pong records (no register
     // rotation), unconditional prefetch (the stream is padded in front).
@@ -138,13 +157,24 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
             const float al = act ? alpha : 0.f;
             const float G = act ? Graw : 0.f;
             float v[16];
-            const float inv = __frcp_rn(1.0f - al);
+            // 1-ulp hardware reciprocal: the correctly rounded 1/x is a ~10-instruction sequence per entry, and the
+            // T recursion is dominated by the rounding of the multiply anyway
+            const float inv = __builtin_amdgcn_rcpf(1.0f - al);
             T = T * inv;
             const float w = al * T;
             float dL_dalpha = 0.f;
+            // dL/dfeature_c = w * dL/dpixel_c (and the depth slot): packed fp32 multiplies, two slots per VALU op
+            {
+                const v2f w2 = {w, w};
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    const v2f t = gp[k] * w2;
+                    v[2 * k] = t.x;
+                    if (2 * k + 1 <= C) v[2 * k + 1] = t.y;
+                }
+            }
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                v[c] = w * g[c];
                 if (c < GC) {
                     const float diff = rec_j.feat(c) - R[c];
                     dL_dalpha += diff * g[c];
@@ -155,26 +185,28 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
                 const float diff = cur[7] - Rd;
                 dL_dalpha += diff * gd;
                 Rd += al * diff;
-                v[C] = w * gd;
             }
             {
                 const float diff = 1.0f - Ra;
                 dL_dalpha += diff * ga;
                 Ra += al * diff;
             }
-            dL_dalpha *= T;
-            dL_dalpha -= T_final * inv * bg_dot;
-            const float dL_dG = opac * dL_dalpha;          // multiplied by G (= 0 for idle lanes) below
-            const float gdx = G * dx, gdy = G * dy;
-            // power = a2*dx^2 + c2*dy^2 + b2*dx*dy with a2 = -A/2, c2 = -C/2, b2 = -B
-            const float dG_ddelx = gdx * (2.f * a2) + gdy * b2;
-            const float dG_ddely = gdy * (2.f * c2) + gdx * b2;
-            v[C + 1] = dL_dG * dG_ddelx * halfW;
-            v[C + 2] = dL_dG * dG_ddely * halfH;
-            v[C + 3] = -0.5f * gdx * dx * dL_dG;
-            v[C + 4] = -0.5f * gdx * dy * dL_dG;
-            v[C + 5] = -0.5f * gdy * dy * dL_dG;
-            v[C + 6] = G * dL_dalpha;
+            dL_dalpha = dL_dalpha * T - inv * tf_bg;
+            // power = a2*dx^2 + c2*dy^2 + b2*dx*dy (a2 = -A/2, c2 = -C/2, b2 = -B):
+            //   dpower/ddx = 2*a2*dx + b2*dy, dpower/ddy = 2*c2*dy + b2*dx, dpower/dA = -dx^2/2, ...
+            // every geometry partial carries the common factor q = opacity * G * dL/dalpha (G = 0 on idle lanes)
+            const float sG = G * dL_dalpha;
+            const float q = opac * sG;
+            const float ppx = (2.f * a2) * dx + b2 * dy;
+            const float ppy = (2.f * c2) * dy + b2 * dx;
+            v[C + 1] = (q * halfW) * ppx;
+            v[C + 2] = (q * halfH) * ppy;
+            const float hq = -0.5f * q;
+            const float hqdx = hq * dx;
+            v[C + 3] = hqdx * dx;
+            v[C + 4] = hqdx * dy;
+            v[C + 5] = (hq * dy) * dy;
+            v[C + 6] = sG;
 #pragma unroll
             for (int k = C + 7; k < 16; ++k) v[k] = 0.f;
             const float y = wave_fold16(v);
