@@ -42,6 +42,19 @@ size_t ogs_kmeans_tmp_bytes(int64_t N, int32_t d, int32_t k);
 int ogs_kmeans_lloyd(const float* feat, int64_t N, int32_t d, float* centers, int32_t k, int32_t k_active,
                      int32_t iters, int32_t nchunks, int64_t* ids_out, int64_t id_offset, void* tmp, void* stream);
 
+/* Sharded Lloyd (new capability, SURVEY.md section 8(e): "k-means shards by point range"): each rank holds a
+ * contiguous range of the points and the (replicated) centres.  One iteration =
+ *     ogs_kmeans_accumulate(my points)        -> table [k, d+1] = per-centre feature sums | point counts
+ *     all-reduce(table, SUM) over the ranks      (k*(d+1) floats: 640 at k = 64, d = 9)
+ *     ogs_kmeans_update(table, ...)            -> centres, with the reference's count rule (see nchunks above)
+ * `tmp` as for ogs_kmeans_lloyd (ogs_kmeans_tmp_bytes(N, d, k)).  `counts_state` [k] is the reference's
+ * persistent `counts` vector: set every entry to 1e-6 before the first iteration (:167) and pass it unchanged
+ * afterwards; `nchunks` is computed from the GLOBAL point count. */
+int ogs_kmeans_accumulate(const float* feat, int64_t N, int32_t d, const float* centers, int32_t k, int32_t k_active,
+                          float* table, void* tmp, void* stream);
+int ogs_kmeans_update(const float* table, int32_t k, int32_t d, int32_t nchunks, float* counts_state, float* centers,
+                      void* stream);
+
 /* ids_out[i] = argmin_j<k ||feat[i] - centers[j]||^2 (first minimum wins, as torch.argmin) + id_offset */
 int ogs_kmeans_assign(const float* feat, int64_t N, int32_t d, const float* centers, int32_t k, int64_t* ids_out,
                       int64_t id_offset, void* stream);

@@ -70,6 +70,8 @@ SIGNATURES = {
     "ogs_kmeans_lloyd": (C.c_int, [_vp, C.c_int64, C.c_int32, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                    _vp, C.c_int64, _vp, _vp]),
     "ogs_kmeans_assign": (C.c_int, [_vp, C.c_int64, C.c_int32, _vp, C.c_int32, _vp, C.c_int64, _vp]),
+    "ogs_kmeans_accumulate": (C.c_int, [_vp, C.c_int64, C.c_int32, _vp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
+    "ogs_kmeans_update": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp]),
     "ogs_kmeans_gather": (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, C.c_int32, _vp, _vp]),
 }
 

@@ -190,17 +190,22 @@ __global__ __launch_bounds__(kBlock) void kmeans_reduce_kernel(const float* __re
 
 // Stage 2: centres = sums / counts with the reference's bookkeeping (kmeans_quantize.py:167,186,209,213-214):
 // counts starts at 1e-6, gains n + 1e-6 per chunk, and is reset to 0 only where it exceeded 0.1.
-__global__ __launch_bounds__(1024) void kmeans_finalize_kernel(const float* __restrict__ slices, int k, int d,
-                                                               float eps_total, float* __restrict__ counts_state,
-                                                               float* __restrict__ centers) {
+// table_out (optional): the summed [k, d+1] table; centers == nullptr: stop after writing it (sharded Lloyd:
+// the caller all-reduces the table over the ranks and feeds it back with nslices == 1).
+__global__ __launch_bounds__(1024) void kmeans_finalize_kernel(const float* __restrict__ slices, int nslices, int k,
+                                                               int d, float eps_total,
+                                                               float* __restrict__ counts_state,
+                                                               float* __restrict__ centers,
+                                                               float* __restrict__ table_out) {
     extern __shared__ float tot[];            // [k*(d+1)]
     const int stride = k * (d + 1);
     for (int e = threadIdx.x; e < stride; e += blockDim.x) {
         float s = 0.f;
-#pragma unroll
-        for (int sl = 0; sl < kSlices; ++sl) s += slices[(size_t)sl * stride + e];
+        for (int sl = 0; sl < nslices; ++sl) s += slices[(size_t)sl * stride + e];
         tot[e] = s;
+        if (table_out) table_out[e] = s;
     }
+    if (centers == nullptr) return;
     __syncthreads();
     for (int e = threadIdx.x; e < k * d; e += blockDim.x) {
         const int c = e / d, jj = e - c * d;
@@ -353,14 +358,56 @@ int ogs_kmeans_lloyd(const float* feat, int64_t N, int32_t d, float* centers, in
         OGS_LAUNCH(kmeans_reduce_kernel, dim3((stride + kBlock - 1) / kBlock, kSlices), dim3(kBlock), 0, s,
                    (const float*)partials, nb, stride, slices);
         OGS_LAUNCH_CHECK(0, s);
-        OGS_LAUNCH(kmeans_finalize_kernel, dim3(1), dim3(1024), fin_lds, s, (const float*)slices, k, d,
-                   (float)nchunks * 1e-6f, counts, centers);
+        OGS_LAUNCH(kmeans_finalize_kernel, dim3(1), dim3(1024), fin_lds, s, (const float*)slices, kSlices, k, d,
+                   (float)nchunks * 1e-6f, counts, centers, (float*)nullptr);
         OGS_LAUNCH_CHECK(0, s);
     }
     if (N > 0) {
         rc = launch_pass<false>(nb, s, feat, N, d, centers, k, k_active, ids_out, id_offset, nullptr);
         if (rc != OGS_OK) return rc;
     }
+    return OGS_OK;
+}
+
+int ogs_kmeans_accumulate(const float* feat, int64_t N, int32_t d, const float* centers, int32_t k, int32_t k_active,
+                          float* table, void* tmp, void* stream_) {
+    int rc = check_dims(N, d, k);
+    if (rc != OGS_OK) return rc;
+    if (k_active < 1 || k_active > k) { set_error("kmeans_accumulate: bad k_active=%d", k_active); return OGS_ERR_INVALID_ARG; }
+    if (!centers || !table || !tmp || (N > 0 && !feat)) { set_error("kmeans_accumulate: NULL pointer"); return OGS_ERR_INVALID_ARG; }
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    const int stride = k * (d + 1);
+    if (N == 0) { OGS_HIP_CHECK(hipMemsetAsync(table, 0, (size_t)stride * sizeof(float), s)); return OGS_OK; }
+    const int nb = pass_blocks(N);
+    float* partials = static_cast<float*>(tmp);
+    float* counts = reinterpret_cast<float*>(static_cast<char*>(tmp) + align_up((size_t)nb * k * (d + 1) * sizeof(float)));
+    float* slices = reinterpret_cast<float*>(reinterpret_cast<char*>(counts) + align_up((size_t)k * sizeof(float)));
+    rc = launch_pass<true>(nb, s, feat, N, d, centers, k, k_active, nullptr, 0, partials);
+    if (rc != OGS_OK) return rc;
+    OGS_LAUNCH(kmeans_reduce_kernel, dim3((stride + kBlock - 1) / kBlock, kSlices), dim3(kBlock), 0, s,
+               (const float*)partials, nb, stride, slices);
+    OGS_LAUNCH_CHECK(0, s);
+    const size_t fin_lds = (size_t)stride * sizeof(float);
+    rc = allow_lds(kmeans_finalize_kernel, fin_lds);
+    if (rc != OGS_OK) return rc;
+    OGS_LAUNCH(kmeans_finalize_kernel, dim3(1), dim3(1024), fin_lds, s, (const float*)slices, kSlices, k, d, 0.f,
+               (float*)nullptr, (float*)nullptr, table);
+    OGS_LAUNCH_CHECK(0, s);
+    return OGS_OK;
+}
+
+int ogs_kmeans_update(const float* table, int32_t k, int32_t d, int32_t nchunks, float* counts_state, float* centers,
+                      void* stream_) {
+    int rc = check_dims(0, d, k);
+    if (rc != OGS_OK) return rc;
+    if (!table || !counts_state || !centers || nchunks < 1) { set_error("kmeans_update: bad arguments"); return OGS_ERR_INVALID_ARG; }
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    const size_t fin_lds = (size_t)k * (d + 1) * sizeof(float);
+    rc = allow_lds(kmeans_finalize_kernel, fin_lds);
+    if (rc != OGS_OK) return rc;
+    OGS_LAUNCH(kmeans_finalize_kernel, dim3(1), dim3(1024), fin_lds, s, table, 1, k, d, (float)nchunks * 1e-6f,
+               counts_state, centers, (float*)nullptr);
+    OGS_LAUNCH_CHECK(0, s);
     return OGS_OK;
 }
 

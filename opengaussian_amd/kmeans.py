@@ -44,6 +44,37 @@ def lloyd(feat: torch.Tensor, centers: torch.Tensor, iters: int, nchunks: int, k
     return ids
 
 
+def lloyd_sharded(feat: torch.Tensor, centers: torch.Tensor, iters: int, nchunks: int, k_active: int | None = None,
+                  id_offset: int = 0, group=None):
+    """Lloyd iterations with the points sharded by range over the ranks of `group`:
+    `feat` holds THIS rank's rows, `centers` [k,d] is replicated and updated in place identically on every rank,
+    `nchunks` is computed from the GLOBAL point count.  Per iteration one HIP pass over the local rows, one
+    all-reduce of the [k, d+1] sums|counts table (640 floats at k=64, d=9) and the centre update with the
+    reference's count rule.  Returns this rank's int64 ids.  With one rank it equals lloyd() up to the order of
+    the fp32 summation."""
+    import torch.distributed as dist
+    _need_gpu(feat, "feat")
+    lib = _lib.lib()
+    f = feat.detach().to(torch.float32).contiguous()
+    if not (centers.is_cuda and centers.dtype == torch.float32 and centers.is_contiguous()):
+        raise RuntimeError("centers must be a contiguous fp32 GPU tensor (updated in place)")
+    N, d = int(f.shape[0]), int(f.shape[1])
+    k = int(centers.shape[0])
+    ka = int(k if k_active is None else k_active)
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    table = torch.empty(k, d + 1, dtype=torch.float32, device=f.device)
+    counts = torch.full((k,), 1e-6, dtype=torch.float32, device=f.device)
+    tmp = torch.empty(int(lib.ogs_kmeans_tmp_bytes(N, d, k)), dtype=torch.uint8, device=f.device)
+    for _ in range(int(iters)):
+        check(lib.ogs_kmeans_accumulate(ptr(f) if N else None, N, d, ptr(centers), k, ka, ptr(table), ptr(tmp),
+                                        _stream()), "ogs_kmeans_accumulate")
+        if multi:
+            dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
+        check(lib.ogs_kmeans_update(ptr(table), k, d, int(nchunks), ptr(counts), ptr(centers), _stream()),
+              "ogs_kmeans_update")
+    return assign(f, centers[:ka], id_offset) if N else torch.empty(0, dtype=torch.int64, device=f.device)
+
+
 def assign(feat: torch.Tensor, centers: torch.Tensor, id_offset: int = 0) -> torch.Tensor:
     """argmin_j ||feat_i - centers_j|| (first minimum wins) as int64 [N]."""
     _need_gpu(feat, "feat")

@@ -136,3 +136,63 @@ def test_full_size_properties(gpu_device):
     cnt = torch.bincount(ids, minlength=k).double()
     torch.testing.assert_close(c2.double(), sums / cnt[:, None], atol=1e-4, rtol=1e-4)
     assert int(cnt.sum()) == N
+
+
+def test_sharded_lloyd_single_rank_equals_fused_lloyd(gpu_device):
+    """ogs_kmeans_accumulate + ogs_kmeans_update (the per-iteration pieces of the point-sharded Lloyd) chain to
+    what ogs_kmeans_lloyd does in one call; leaf mode (k_active < k, id offset) included."""
+    from opengaussian_amd import kmeans as km
+    g = torch.Generator().manual_seed(4)
+    for (N, d, k, ka, off) in [(30000, 9, 64, 64, 0), (5000, 6, 10, 7, 130)]:
+        feat = torch.rand(N, d, generator=g).to(gpu_device)
+        init = feat[torch.randperm(N, generator=g)[:k].to(gpu_device)].clone()
+        nch = N // 10000 + 1
+        c1, c2 = init.clone(), init.clone()
+        ids1 = km.lloyd(feat, c1, 5, nch, k_active=ka, id_offset=off)
+        ids2 = km.lloyd_sharded(feat, c2, 5, nch, k_active=ka, id_offset=off)
+        torch.testing.assert_close(c2, c1, rtol=1e-5, atol=1e-6)
+        assert float((ids1 != ids2).float().mean()) < 1e-3
+        assert int(ids2.min()) >= off and int(ids2.max()) < off + ka
+
+
+def _kmeans_rank(rank, world, port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), OGS_DIST_BACKEND="gloo")
+    import torch.distributed as dist
+    from opengaussian_amd import dp, kmeans as km
+    dp.init_from_env("cuda")
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(8)
+    N, d, k = 40001, 9, 64
+    feat = torch.rand(N, d, generator=g)
+    init = feat[torch.randperm(N, generator=g)[:k]].clone()
+    lo, hi = rank * N // world, (rank + 1) * N // world
+    c = init.clone().to(dev)
+    ids = km.lloyd_sharded(feat[lo:hi].to(dev), c, 5, N // 10000 + 1)
+    # single-process truth on the full point set
+    c_ref = init.clone().to(dev)
+    ids_ref = km.lloyd(feat.to(dev), c_ref, 5, N // 10000 + 1)
+    err = float((c - c_ref).abs().max())
+    mism = float((ids != ids_ref[lo:hi]).float().mean())
+    q.put((rank, err, mism))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_lloyd_two_ranks_match_single_process(gpu_device):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_kmeans_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err, mism in res:
+        assert err < 1e-4, (rank, err)          # fp32 summation order differs (per-rank partial tables)
+        assert mism < 1e-3, (rank, mism)
