@@ -81,6 +81,15 @@ typedef struct OgsRasterFwdArgs {
     void* binning_tmp;           /* ogs_raster_binning_tmp_bytes(num_rendered, W, H) (render phase) */
     void* sorted_rec;            /* ogs_raster_sorted_bytes(num_rendered, C): packed per-tile record stream the
                                     blend kernels read through the scalar path; kept until backward */
+    /* Grouped pass ("batched subset rendering via a per-Gaussian group_id"): with
+     * num_groups = G > 1 the pass renders G independent images in one go -- image g blends exactly the
+     * Gaussians with group_ids[p] == g, i.e. what G separate calls on the boolean-indexed subsets
+     * (gaussian_renderer/__init__.py:203-225,327-345) would return -- sharing one preprocess, one sort and one
+     * launch sequence.  out_color is then [G,C,H,W], out_depth / out_alpha [G,1,H,W], image_buffer
+     * ogs_raster_image_bytes_grouped(W, H, G); Gaussians with a group id outside [0, G) are not rendered
+     * (radius 0).  num_groups <= 1 (and group_ids == NULL): the plain single-image pass. */
+    const int32_t* group_ids;    /* [P] or NULL */
+    int32_t num_groups;          /* 0 or 1: ungrouped */
 } OgsRasterFwdArgs;
 
 /* Arguments of the backward pass.  Mirrors upstream rasterize_gaussians_backward(bg, means3D,
@@ -126,6 +135,8 @@ typedef struct OgsRasterBwdArgs {
     float* dL_dsh;               /* [P,M,3] (when shs was the input) */
     float* dL_dscales;           /* [P,3] */
     float* dL_drotations;        /* [P,4] */
+    int32_t num_groups;          /* as in the forward pass (0/1: ungrouped): dL_dcolor is [G,C,H,W], dL_ddepth /
+                                    dL_dalpha / out_alpha [G,1,H,W] */
     float* dL_dsh_rgb;           /* [P,3] optional (shs input only): gradient w.r.t. the SH-evaluated RGB after the
                                     clamp mask, zero for culled Gaussians.  Per view dL/dsh[p,m,:] = Y_m(dir(p)) *
                                     dL_dsh_rgb[p,:] (rank 1), so a data-parallel caller can pass dL_dsh = NULL,
@@ -139,6 +150,7 @@ const char* ogs_last_error(void);
 size_t ogs_raster_geom_bytes(int32_t P, int32_t C);
 size_t ogs_raster_geom_tmp_bytes(int32_t P);
 size_t ogs_raster_image_bytes(int32_t W, int32_t H);
+size_t ogs_raster_image_bytes_grouped(int32_t W, int32_t H, int32_t num_groups);
 size_t ogs_raster_binning_tmp_bytes(int64_t num_rendered, int32_t W, int32_t H);
 size_t ogs_raster_backward_tmp_bytes(int32_t P);
 size_t ogs_raster_sorted_bytes(int64_t num_rendered, int32_t C);

@@ -82,7 +82,7 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 // features): a runtime value turned every per-channel update into v_cndmask selects and kept dead math alive.
 template <int C, int GC>
 __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
-    const uint2* __restrict__ ranges, const float* __restrict__ stream, int W, int H, int gx,
+    const uint2* __restrict__ ranges, const float* __restrict__ stream, int W, int H, int gx, int tiles,
     const float* __restrict__ bg, const float* __restrict__ out_alpha, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha_map,
     float* __restrict__ grad_rec) {
@@ -90,15 +90,17 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     constexpr int GS = grad_stride(C);
     static_assert(C + 7 <= 16, "gradient record must fit 16 slots");
 
-    const int tile = blockIdx.x;
-    const int tx = tile % gx, ty = tile / gx;
+    const int tile = blockIdx.x;                // virtual tile (grouped pass): image * tiles + tile in the image
+    const int img = tile / tiles, timg = tile - img * tiles;
+    const int tx = timg % gx, ty = timg / gx;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int px = tx * kTile + (wave & 1) * 8 + (lane & 7);
     const int py = ty * kTile + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = px < W && py < H;
     const float fx = (float)px, fy = (float)py;
-    const size_t pix = (size_t)py * W + px;
     const size_t plane = (size_t)W * H;
+    const size_t pix = (size_t)img * plane + (size_t)py * W + px;       // pixel of image `img` in [G,1,H,W] maps
+    dL_dcolor += (size_t)img * (C - 1) * plane;                         // + pix: image stride of [G,C,H,W] is C planes
 
     const uint2 range = ranges[tile];
     const int last_contrib = inside ? (int)n_contrib[pix] : 0;
@@ -242,13 +244,14 @@ int launch_c(const OgsRasterBwdArgs& a, const ImageState& is, float* grad_rec, h
     static constexpr const char* const kNames[4] = {"blend_backward_kernel<3>", "blend_backward_kernel<6>",
                                                     "blend_backward_kernel<9>", "blend_backward_kernel<12>"};
     const float* stream = (const float*)stream_base<C>(const_cast<void*>(a.sorted_rec));
+    const unsigned vtiles = (unsigned)(gx * gy) * (unsigned)num_groups_of(a.num_groups);
     if (a.geom_channels <= 0 || a.geom_channels >= C) {
-        OGS_LAUNCH_NAMED(chan_name<C>(kNames), (blend_backward_kernel<C, C>), dim3(gx * gy), dim3(kBlock), 0, s,
-                         (const uint2*)is.ranges, stream, a.W, a.H, gx, a.bg, a.out_alpha, (const uint32_t*)is.n_contrib,
+        OGS_LAUNCH_NAMED(chan_name<C>(kNames), (blend_backward_kernel<C, C>), dim3(vtiles), dim3(kBlock), 0, s,
+                         (const uint2*)is.ranges, stream, a.W, a.H, gx, gx * gy, a.bg, a.out_alpha, (const uint32_t*)is.n_contrib,
                          a.dL_dcolor, a.dL_ddepth, a.dL_dalpha, grad_rec);
     } else if (a.geom_channels == 3) {
-        OGS_LAUNCH_NAMED(chan_name<C>(kNames), (blend_backward_kernel<C, 3>), dim3(gx * gy), dim3(kBlock), 0, s,
-                         (const uint2*)is.ranges, stream, a.W, a.H, gx, a.bg, a.out_alpha, (const uint32_t*)is.n_contrib,
+        OGS_LAUNCH_NAMED(chan_name<C>(kNames), (blend_backward_kernel<C, 3>), dim3(vtiles), dim3(kBlock), 0, s,
+                         (const uint2*)is.ranges, stream, a.W, a.H, gx, gx * gy, a.bg, a.out_alpha, (const uint32_t*)is.n_contrib,
                          a.dL_dcolor, a.dL_ddepth, a.dL_dalpha, grad_rec);
     } else {
         set_error("backward: geom_channels must be 0, 3 or C (got %d with C=%d)", a.geom_channels, C);

@@ -53,17 +53,18 @@ __device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d) {
 template <int C>
 __global__ __launch_bounds__(kBlock) void pack_sorted_kernel(const uint2* __restrict__ ranges,
                                                              const uint32_t* __restrict__ point_list, int gx,
-                                                             const float4* __restrict__ rec,
+                                                             int tiles, const float4* __restrict__ rec,
                                                              float4* __restrict__ stream,
                                                              uint32_t* __restrict__ qcount) {
     constexpr int NV = rec_vec4(C);
     constexpr int SV = stream_vec4(C);
     __shared__ uint64_t wave_tot[kBlock / kWave];
-    const int tile = blockIdx.x;
+    const int tile = blockIdx.x;                           // virtual tile: image (group) * tiles + tile in the image
+    const int timg = tile % tiles;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
-    const float X0 = (float)((tile % gx) * kTile), Y0 = (float)((tile / gx) * kTile);
+    const float X0 = (float)((timg % gx) * kTile), Y0 = (float)((timg / gx) * kTile);
     uint32_t running[4] = {0u, 0u, 0u, 0u};                // kept entries per quadrant so far (block-uniform)
 
     for (int base = 0; base < n; base += kBlock) {
@@ -144,11 +145,12 @@ __global__ __launch_bounds__(kBlock) void pack_sorted_kernel(const uint2* __rest
 template <int C>
 __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ qcount, const float* __restrict__ stream, int W,
-    int H, int gx, const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ out_depth,
-    float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib) {
+    int H, int gx, int tiles, const float* __restrict__ bg, float* __restrict__ out_color,
+    float* __restrict__ out_depth, float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib) {
     constexpr int RS = stream_vec4(C) * 4;      // floats per stream record
-    const int tile = blockIdx.x;
-    const int tx = tile % gx, ty = tile / gx;
+    const int tile = blockIdx.x;                // virtual tile (grouped pass): image * tiles + tile in the image
+    const int img = tile / tiles, timg = tile - img * tiles;
+    const int tx = timg % gx, ty = timg / gx;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int px = tx * kTile + (wave & 1) * 8 + (lane & 7);
     const int py = ty * kTile + (wave >> 1) * 8 + (lane >> 3);
@@ -215,10 +217,11 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
     }
 
     if (inside) {
-        const size_t pix = (size_t)py * W + px;
         const size_t plane = (size_t)W * H;
+        const size_t pix = (size_t)img * plane + (size_t)py * W + px;       // pixel of image `img`
+        float* oc = out_color + (size_t)img * (C - 1) * plane;               // + pix: image stride is C planes
 #pragma unroll
-        for (int c = 0; c < C; ++c) out_color[c * plane + pix] = acc[c] + T * bg[c];
+        for (int c = 0; c < C; ++c) oc[c * plane + pix] = acc[c] + T * bg[c];
         out_depth[pix] = dacc;
         out_alpha[pix] = wacc;
         n_contrib[pix] = last;          // index into the QUADRANT stream (+1); see export_n_contrib_kernel
@@ -231,17 +234,20 @@ template <int C>
 __global__ __launch_bounds__(kBlock) void export_n_contrib_kernel(const uint2* __restrict__ ranges,
                                                                   const uint32_t* __restrict__ point_list,
                                                                   const float* __restrict__ stream, int W, int H, int gx,
-                                                                  const uint32_t* __restrict__ n_contrib,
+                                                                  int tiles, const uint32_t* __restrict__ n_contrib,
                                                                   uint32_t* __restrict__ out) {
     constexpr int RS = stream_vec4(C) * 4;
     const int tile = blockIdx.x;
-    const int tx = tile % gx, ty = tile / gx;
+    const int img = tile / tiles, timg = tile - img * tiles;
+    const int tx = timg % gx, ty = timg / gx;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int px = tx * kTile + (wave & 1) * 8 + (lane & 7);
     const int py = ty * kTile + (wave >> 1) * 8 + (lane >> 3);
     if (px >= W || py >= H) return;
     const uint2 range = ranges[tile];
     const int n_tile = (int)(range.y - range.x);
+    n_contrib += (size_t)img * W * H;
+    out += (size_t)img * W * H;
     const uint32_t last = n_contrib[(size_t)py * W + px];
     uint32_t res = 0;
     if (last > 0) {
@@ -256,21 +262,23 @@ __global__ __launch_bounds__(kBlock) void export_n_contrib_kernel(const uint2* _
 template <int C>
 int launch_c(const OgsRasterFwdArgs& a, const GeomState& gs, const ImageState& is, int64_t D, hipStream_t s) {
     const int gx = (a.W + kTile - 1) / kTile, gy = (a.H + kTile - 1) / kTile;
+    const int tiles = gx * gy;
+    const unsigned vtiles = (unsigned)tiles * (unsigned)num_groups_of(a.num_groups);
     if (D > 0) {
         static constexpr const char* const kPack[4] = {"pack_sorted_kernel<3>", "pack_sorted_kernel<6>",
                                                        "pack_sorted_kernel<9>", "pack_sorted_kernel<12>"};
-        OGS_LAUNCH_NAMED(chan_name<C>(kPack), pack_sorted_kernel<C>, dim3(gx * gy), dim3(kBlock), 0, s,
-                         (const uint2*)is.ranges, (const uint32_t*)a.point_list, gx, (const float4*)gs.rec,
+        OGS_LAUNCH_NAMED(chan_name<C>(kPack), pack_sorted_kernel<C>, dim3(vtiles), dim3(kBlock), 0, s,
+                         (const uint2*)is.ranges, (const uint32_t*)a.point_list, gx, tiles, (const float4*)gs.rec,
                          stream_base<C>(a.sorted_rec), is.qcount);
         OGS_LAUNCH_CHECK(a.debug, s);
     } else {
-        OGS_HIP_CHECK(hipMemsetAsync(is.qcount, 0, (size_t)gx * gy * 4 * sizeof(uint32_t), s));
+        OGS_HIP_CHECK(hipMemsetAsync(is.qcount, 0, (size_t)vtiles * 4 * sizeof(uint32_t), s));
     }
     static constexpr const char* const kNames[4] = {"blend_forward_kernel<3>", "blend_forward_kernel<6>",
                                                     "blend_forward_kernel<9>", "blend_forward_kernel<12>"};
-    OGS_LAUNCH_NAMED(chan_name<C>(kNames), blend_forward_kernel<C>, dim3(gx * gy), dim3(kBlock), 0, s,
+    OGS_LAUNCH_NAMED(chan_name<C>(kNames), blend_forward_kernel<C>, dim3(vtiles), dim3(kBlock), 0, s,
                      (const uint2*)is.ranges, (const uint32_t*)is.qcount, (const float*)stream_base<C>(a.sorted_rec), a.W,
-                     a.H, gx, a.bg, a.out_color, a.out_depth, a.out_alpha, is.n_contrib);
+                     a.H, gx, tiles, a.bg, a.out_color, a.out_depth, a.out_alpha, is.n_contrib);
     OGS_LAUNCH_CHECK(a.debug, s);
     return OGS_OK;
 }
@@ -278,9 +286,9 @@ int launch_c(const OgsRasterFwdArgs& a, const GeomState& gs, const ImageState& i
 template <int C>
 int export_c(const OgsRasterFwdArgs& a, const ImageState& is, uint32_t* out, hipStream_t s) {
     const int gx = (a.W + kTile - 1) / kTile, gy = (a.H + kTile - 1) / kTile;
-    OGS_LAUNCH(export_n_contrib_kernel<C>, dim3(gx * gy), dim3(kBlock), 0, s, (const uint2*)is.ranges,
-               (const uint32_t*)a.point_list, (const float*)stream_base<C>(a.sorted_rec), a.W, a.H, gx,
-               (const uint32_t*)is.n_contrib, out);
+    OGS_LAUNCH(export_n_contrib_kernel<C>, dim3((unsigned)(gx * gy) * (unsigned)num_groups_of(a.num_groups)), dim3(kBlock), 0,
+               s, (const uint2*)is.ranges, (const uint32_t*)a.point_list, (const float*)stream_base<C>(a.sorted_rec), a.W,
+               a.H, gx, gx * gy, (const uint32_t*)is.n_contrib, out);
     OGS_LAUNCH_CHECK(0, s);
     return OGS_OK;
 }

@@ -83,6 +83,9 @@ static int validate_fwd(const OgsRasterFwdArgs* a) {
     if (a->P > 0 && (!a->means3D || !a->opacities || !a->radii || !a->geom_buffer || !a->geom_tmp)) {
         set_error("NULL required per-Gaussian pointer"); return OGS_ERR_INVALID_ARG;
     }
+    if (a->num_groups < 0 || (a->num_groups > 1 && a->P > 0 && !a->group_ids)) {
+        set_error("num_groups=%d needs group_ids", a->num_groups); return OGS_ERR_INVALID_ARG;
+    }
     return OGS_OK;
 }
 
@@ -137,6 +140,7 @@ const char* ogs_last_error(void) { return g_err; }
 size_t ogs_raster_geom_bytes(int32_t P, int32_t C) { return GeomState::bytes(P > 0 ? P : 1, C); }
 size_t ogs_raster_geom_tmp_bytes(int32_t P) { return GeomTmp::bytes(P > 0 ? P : 1); }
 size_t ogs_raster_image_bytes(int32_t W, int32_t H) { return ImageState::bytes(W, H); }
+size_t ogs_raster_image_bytes_grouped(int32_t W, int32_t H, int32_t G) { return ImageState::bytes(W, H, num_groups_of(G)); }
 size_t ogs_raster_binning_tmp_bytes(int64_t D, int32_t, int32_t) { return BinTmp::bytes(D > 0 ? D : 1); }
 size_t ogs_raster_sorted_bytes(int64_t D, int32_t C) {
     // every tile owns four quadrant regions of capacity n_tile each (only the kept ~1.1 x D records are touched)
@@ -186,9 +190,11 @@ int ogs_raster_read_num_rendered_async(const OgsRasterFwdArgs* a, void* stream_,
 static int render_impl(const OgsRasterFwdArgs* a, int64_t D, bool deferred, hipStream_t s) {
     int rc = validate_fwd(a);
     if (rc != OGS_OK) return rc;
-    const ImageState is = ImageState::carve(a->image_buffer, a->W, a->H);
+    const int G = num_groups_of(a->num_groups);
+    const ImageState is = ImageState::carve(a->image_buffer, a->W, a->H, G);
     const int gx = (a->W + kTile - 1) / kTile, gy = (a->H + kTile - 1) / kTile;
-    const int tiles = gx * gy;
+    const int64_t tiles = (int64_t)gx * gy * G;             // virtual tiles: image (group) * tiles_per_image + tile
+    if (tiles >= (1ll << 31)) { set_error("%d groups x %d tiles exceed 2^31 virtual tiles", G, gx * gy); return OGS_ERR_UNSUPPORTED; }
     const GeomState gs = GeomState::carve(a->geom_buffer, a->P > 0 ? a->P : 1, a->C);
     if (D > 0) {
         if (!a->point_list || !a->binning_tmp) { set_error("point_list / binning_tmp == NULL with num_rendered=%lld", (long long)D); return OGS_ERR_INVALID_ARG; }
@@ -241,7 +247,8 @@ int ogs_raster_backward(const OgsRasterBwdArgs* a, void* stream_) {
     if (a->num_rendered > 0 && !a->point_list) { set_error("backward: point_list == NULL"); return OGS_ERR_INVALID_ARG; }
     hipStream_t s = static_cast<hipStream_t>(stream_);
     const GeomState gs = GeomState::carve(const_cast<void*>(a->geom_buffer), a->P, a->C);
-    const ImageState is = ImageState::carve(const_cast<void*>(a->image_buffer), a->W, a->H);
+    if (a->num_groups < 0) { set_error("backward: num_groups=%d", a->num_groups); return OGS_ERR_INVALID_ARG; }
+    const ImageState is = ImageState::carve(const_cast<void*>(a->image_buffer), a->W, a->H, num_groups_of(a->num_groups));
     float* grad_rec = static_cast<float*>(a->bwd_tmp);
     OGS_HIP_CHECK(hipMemsetAsync(grad_rec, 0, (size_t)a->P * grad_stride(a->C) * sizeof(float), s));
     if (a->num_rendered > 0 && !a->sorted_rec) { set_error("backward: sorted_rec == NULL"); return OGS_ERR_INVALID_ARG; }
@@ -280,21 +287,22 @@ int ogs_raster_export_binning(const OgsRasterFwdArgs* a, int64_t D, uint64_t* ke
                               uint32_t* n_contrib_out, void* stream_) {
     if (!a) { set_error("args == NULL"); return OGS_ERR_INVALID_ARG; }
     hipStream_t s = static_cast<hipStream_t>(stream_);
-    const ImageState is = ImageState::carve(a->image_buffer, a->W, a->H);
+    const int G = num_groups_of(a->num_groups);     // grouped pass: everything below is per VIRTUAL tile / image
+    const ImageState is = ImageState::carve(a->image_buffer, a->W, a->H, G);
     const int gx = (a->W + kTile - 1) / kTile, gy = (a->H + kTile - 1) / kTile;
     if (keys_out && D > 0) {
         const GeomState gs = GeomState::carve(a->geom_buffer, a->P, a->C);
-        int rc = launch_export_keys(is.ranges, gx * gy, a->point_list, gs.rec, rec_vec4(a->C), keys_out, s);
+        int rc = launch_export_keys(is.ranges, gx * gy * G, a->point_list, gs.rec, rec_vec4(a->C), keys_out, s);
         if (rc != OGS_OK) return rc;
     }
     if (ranges_out)
-        OGS_HIP_CHECK(hipMemcpyAsync(ranges_out, is.ranges, (size_t)gx * gy * sizeof(uint2), hipMemcpyDeviceToDevice, s));
+        OGS_HIP_CHECK(hipMemcpyAsync(ranges_out, is.ranges, (size_t)gx * gy * G * sizeof(uint2), hipMemcpyDeviceToDevice, s));
     if (n_contrib_out) {
         if (D > 0) {
             int rc = launch_export_n_contrib(*a, is, n_contrib_out, s);
             if (rc != OGS_OK) return rc;
         } else {
-            OGS_HIP_CHECK(hipMemsetAsync(n_contrib_out, 0, (size_t)a->W * a->H * sizeof(uint32_t), s));
+            OGS_HIP_CHECK(hipMemsetAsync(n_contrib_out, 0, (size_t)G * a->W * a->H * sizeof(uint32_t), s));
         }
     }
     return OGS_OK;

@@ -146,21 +146,22 @@ struct ImageState {     // kept until backward
     uint2* ranges;          // [tiles] range of the tile in the sorted list (reference-exact)
     uint32_t* n_contrib;    // [W*H] last contributor, as 1-based index into the pixel's QUADRANT stream
     uint32_t* qcount;       // [tiles*4] entries kept in each 8x8 quadrant stream
-    static ImageState carve(void* p, int W, int H) {
+    // G images of a grouped pass are G * tiles "virtual tiles": virtual tile vt = g * tiles + t
+    static ImageState carve(void* p, int W, int H, int G = 1) {
         Carver c(p);
         ImageState s;
-        int tiles = ((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile);
+        const size_t tiles = (size_t)G * ((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile);
         s.ranges = c.take<uint2>(tiles);
-        s.n_contrib = c.take<uint32_t>((size_t)W * H);
-        s.qcount = c.take<uint32_t>((size_t)tiles * 4);
+        s.n_contrib = c.take<uint32_t>((size_t)G * W * H);
+        s.qcount = c.take<uint32_t>(tiles * 4);
         return s;
     }
-    static size_t bytes(int W, int H) {
+    static size_t bytes(int W, int H, int G = 1) {
         Carver c(nullptr);
-        int tiles = ((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile);
+        const size_t tiles = (size_t)G * ((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile);
         c.take<uint2>(tiles);
-        c.take<uint32_t>((size_t)W * H);
-        c.take<uint32_t>((size_t)tiles * 4);
+        c.take<uint32_t>((size_t)G * W * H);
+        c.take<uint32_t>(tiles * 4);
         return c.off;
     }
 };
@@ -236,8 +237,9 @@ struct BinTmp {         // transient, render phase
 int launch_preprocess(const OgsRasterFwdArgs& a, const GeomState& gs, const GeomTmp& gt, hipStream_t s);
 int launch_duplicate(const OgsRasterFwdArgs& a, const GeomState& gs, const GeomTmp& gt, uint32_t* tile_keys,
                      uint32_t* vals, uint32_t capacity, hipStream_t s);
-int launch_tile_ranges(const uint32_t* tile_keys_sorted, int64_t D, uint2* ranges, int tiles, hipStream_t s,
+int launch_tile_ranges(const uint32_t* tile_keys_sorted, int64_t D, uint2* ranges, int64_t tiles, hipStream_t s,
                        int debug, const uint32_t* n_dev = nullptr);
+inline int num_groups_of(int g) { return g > 1 ? g : 1; }
 int launch_blend_forward(const OgsRasterFwdArgs& a, const GeomState& gs, const ImageState& is, int64_t D,
                          hipStream_t s);
 int launch_blend_backward(const OgsRasterBwdArgs& a, const ImageState& is, float* grad_rec, hipStream_t s);

@@ -98,7 +98,8 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix,
     const float* __restrict__ projmatrix, const float* __restrict__ campos, float4* __restrict__ rec,
     uint32_t* __restrict__ clamped_out, int32_t* __restrict__ radii, uint32_t* __restrict__ tiles_touched,
-    uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ order) {
+    uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ order, const int32_t* __restrict__ group_ids,
+    int num_groups) {
     constexpr int NV = rec_vec4(C);
     const int idx = blockIdx.x * kBlock + threadIdx.x;
     if (idx >= P) return;
@@ -126,6 +127,8 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(
     const float pvy = V[1] * x + V[5] * y + V[9] * z + V[13];
     const float pvz = V[2] * x + V[6] * y + V[10] * z + V[14];
     bool ok = pvz > 0.2f;
+    // grouped pass: a Gaussian outside every group is not rendered at all
+    if (group_ids != nullptr) ok = ok && (uint32_t)group_ids[idx] < (uint32_t)num_groups;
     if (ok) {
         // 2. clip space
         const float hx = M[0] * x + M[4] * y + M[8] * z + M[12];
@@ -246,7 +249,9 @@ __global__ __launch_bounds__(kBlock) void duplicate_kernel(int P, int W, int H, 
                                                            const uint32_t* __restrict__ order,
                                                            const uint32_t* __restrict__ offsets,
                                                            uint32_t* __restrict__ tile_keys,
-                                                           uint32_t* __restrict__ vals, uint32_t capacity) {
+                                                           uint32_t* __restrict__ vals, uint32_t capacity,
+                                                           const int32_t* __restrict__ group_ids) {
+    // group_ids != nullptr (grouped pass): the key is the VIRTUAL tile group * tiles + tile
     // capacity: size of tile_keys / vals.  In the deferred render phase it is a cached estimate and the true
     // num_rendered may exceed it: such entries are dropped here and the host re-runs the phase (rasterizer.py).
     //
@@ -259,13 +264,16 @@ __global__ __launch_bounds__(kBlock) void duplicate_kernel(int P, int W, int H, 
     __shared__ uint32_t s_gid[kBlock];
     __shared__ uint32_t s_rect[kBlock];     // rminx | rminy << 12 | width << 24   (grids up to 4095 tiles a side)
     __shared__ uint32_t s_first, s_total;
+    __shared__ uint32_t s_key0[kBlock];     // group * tiles: first virtual tile of the Gaussian's image
     const int tid = threadIdx.x;
     const int r = blockIdx.x * kBlock + tid;
     const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
-    uint32_t off = 0, cnt = 0, gid = 0, rect = 1u << 24;
+    uint32_t off = 0, cnt = 0, gid = 0, rect = 1u << 24, key0 = 0;
     if (r < P) {
         gid = order[r];
         off = offsets[r];
+        // culled Gaussians (radius 0) may carry any group id: they emit nothing
+        if (group_ids != nullptr) key0 = (uint32_t)max(group_ids[gid], 0) * (uint32_t)(gx * gy);
         const float4 a = rec[(size_t)gid * NV];
         const int radius = __float_as_int(a.w);
         if (radius > 0) {
@@ -288,7 +296,7 @@ __global__ __launch_bounds__(kBlock) void duplicate_kernel(int P, int W, int H, 
                     uint32_t o = off;
                     for (int ty = rminy; ty < rmaxy; ++ty)
                         for (int tx = rminx; tx < rmaxx; ++tx) {
-                            if (o < capacity) { tile_keys[o] = (uint32_t)(ty * gx + tx); vals[o] = gid; }
+                            if (o < capacity) { tile_keys[o] = key0 + (uint32_t)(ty * gx + tx); vals[o] = gid; }
                             ++o;
                         }
                     rect |= 0u;            // slots of this Gaussian are skipped in the cooperative walk (marked below)
@@ -304,6 +312,7 @@ __global__ __launch_bounds__(kBlock) void duplicate_kernel(int P, int W, int H, 
     s_off[tid] = (r < P) ? off - first : 0xFFFFFFFFu;
     s_gid[tid] = gid;
     s_rect[tid] = rect;
+    s_key0[tid] = key0;
     const int last = min(P - 1 - blockIdx.x * kBlock, kBlock - 1);
     if (tid == last) s_total = off - first + cnt;
     __syncthreads();
@@ -324,7 +333,7 @@ __global__ __launch_bounds__(kBlock) void duplicate_kernel(int P, int W, int H, 
         const uint32_t row = local / w, col = local - row * w;
         const uint32_t o = first + j;
         if (o < capacity) {
-            tile_keys[o] = ((rc >> 12 & 0xFFFu) + row) * (uint32_t)gx + (rc & 0xFFFu) + col;
+            tile_keys[o] = s_key0[lo] + ((rc >> 12 & 0xFFFu) + row) * (uint32_t)gx + (rc & 0xFFFu) + col;
             vals[o] = g;
         }
     }
@@ -349,7 +358,8 @@ int launch_preprocess_c(const OgsRasterFwdArgs& a, const GeomState& gs, const Ge
     OGS_LAUNCH_NAMED(chan_name<C>(kNames), preprocess_kernel<C>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, a.sh_degree, a.sh_coeffs,
                        a.tanfovx, a.tanfovy, focal_x, focal_y, a.scale_modifier, a.means3D, a.colors_precomp, a.shs,
                        a.opacities, a.scales, a.rotations, a.cov3D_precomp, a.viewmatrix, a.projmatrix, a.campos,
-                       gs.rec, gs.clamped, a.radii, gt.tiles_touched, gt.keys[0], gt.order[0]);
+                       gs.rec, gs.clamped, a.radii, gt.tiles_touched, gt.keys[0], gt.order[0],
+                       a.num_groups > 1 ? a.group_ids : (const int32_t*)nullptr, a.num_groups);
     OGS_LAUNCH_CHECK(a.debug, s);
     return OGS_OK;
 }
@@ -369,14 +379,15 @@ int launch_preprocess(const OgsRasterFwdArgs& a, const GeomState& gs, const Geom
 int launch_duplicate(const OgsRasterFwdArgs& a, const GeomState& gs, const GeomTmp& gt, uint32_t* tile_keys,
                      uint32_t* vals, uint32_t capacity, hipStream_t s) {
     const int grid = (a.P + kBlock - 1) / kBlock;
+    const int32_t* grp = a.num_groups > 1 ? a.group_ids : nullptr;
     if ((a.W + kTile - 1) / kTile > 4095 || (a.H + kTile - 1) / kTile > 4095) {
         set_error("image %dx%d exceeds 4095 tiles per side", a.W, a.H);
         return OGS_ERR_UNSUPPORTED;
     }
     switch (rec_vec4(a.C)) {
-        case 3: OGS_LAUNCH(duplicate_kernel<3>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals, capacity); break;
-        case 4: OGS_LAUNCH(duplicate_kernel<4>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals, capacity); break;
-        case 5: OGS_LAUNCH(duplicate_kernel<5>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals, capacity); break;
+        case 3: OGS_LAUNCH(duplicate_kernel<3>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals, capacity, grp); break;
+        case 4: OGS_LAUNCH(duplicate_kernel<4>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals, capacity, grp); break;
+        case 5: OGS_LAUNCH(duplicate_kernel<5>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals, capacity, grp); break;
         default: set_error("unsupported record size"); return OGS_ERR_UNSUPPORTED;
     }
     OGS_LAUNCH_CHECK(a.debug, s);

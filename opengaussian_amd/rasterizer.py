@@ -62,10 +62,19 @@ def _require_gpu(t: torch.Tensor, name: str):
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings: GaussianRasterizationSettings, geom_channels: int = 0, sh_rgb_sink=None):
+                raster_settings: GaussianRasterizationSettings, geom_channels: int = 0, sh_rgb_sink=None,
+                group_ids=None, num_groups: int = 1):
         rs = raster_settings
         ctx.geom_channels = int(geom_channels)
         ctx.sh_rgb_sink = sh_rgb_sink
+        G = max(int(num_groups), 1)
+        ctx.num_groups = G
+        if G > 1:
+            if group_ids is None or group_ids.shape[0] != means3D.shape[0]:
+                raise RuntimeError("a grouped pass needs group_ids [P]")
+            group_ids = group_ids.detach().to(device=means3D.device, dtype=torch.int32).contiguous()
+        else:
+            group_ids = None
         _require_gpu(means3D, "means3D")
         dev = means3D.device
         lib = _lib.lib()
@@ -101,9 +110,10 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         # P > 0: the kernels write every pixel of every tile and every radius, so no fill pass is needed
         alloc = torch.zeros if P == 0 else torch.empty
-        color = alloc(Cn, H, W, dtype=torch.float32, device=dev)
-        depth = alloc(1, H, W, dtype=torch.float32, device=dev)
-        alpha = alloc(1, H, W, dtype=torch.float32, device=dev)
+        lead = (G,) if G > 1 else ()           # grouped pass: one image per group
+        color = alloc(*lead, Cn, H, W, dtype=torch.float32, device=dev)
+        depth = alloc(*lead, 1, H, W, dtype=torch.float32, device=dev)
+        alpha = alloc(*lead, 1, H, W, dtype=torch.float32, device=dev)
         radii = alloc(P, dtype=torch.int32, device=dev)
         ctx.raster_settings = rs
         ctx.P, ctx.Cn, ctx.num_rendered = P, Cn, 0
@@ -116,7 +126,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         u8 = lambda n: torch.empty(int(n), dtype=torch.uint8, device=dev)
         geom = u8(lib.ogs_raster_geom_bytes(P, Cn))
         geom_tmp = u8(lib.ogs_raster_geom_tmp_bytes(P))
-        image = u8(lib.ogs_raster_image_bytes(W, H))
+        image = u8(lib.ogs_raster_image_bytes_grouped(W, H, G))
 
         a = OgsRasterFwdArgs()
         a.P, a.W, a.H, a.C = P, W, H, Cn
@@ -129,6 +139,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         a.viewmatrix, a.projmatrix, a.campos = ptr(view), ptr(proj), ptr(campos)
         a.out_color, a.out_depth, a.out_alpha, a.radii = ptr(color), ptr(depth), ptr(alpha), ptr(radii)
         a.geom_buffer, a.geom_tmp, a.image_buffer = ptr(geom), ptr(geom_tmp), ptr(image)
+        a.group_ids, a.num_groups = ptr(group_ids), G
 
         stream = _stream()
 
@@ -139,7 +150,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             a.point_list, a.binning_tmp, a.sorted_rec = ptr(pl), ptr(bt), ptr(sr)
             return pl, bt, sr
 
-        key = (P, W, H)
+        key = (P, W, H, G)
         last = _LAST_NUM_RENDERED.get(key)
         if last is None or rs.debug:
             # first pass at this size: blocking 4-byte read-back of num_rendered (what the reference does every time)
@@ -181,7 +192,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         P, Cn = ctx.P, ctx.Cn
         if P == 0:
-            return (None,) * 11
+            return (None,) * 13
         (m3, shs, cols, opac, scl, rot, cov, bg, view, proj, campos, radii, alpha, geom, image,
          point_list, sorted_rec) = ctx.saved_tensors
         dev = m3.device
@@ -204,7 +215,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         gc = _f32c(grad_color)
         if gc is None:
-            gc = torch.zeros(Cn, H, W, dtype=torch.float32, device=dev)
+            gc = torch.zeros(*((ctx.num_groups,) if ctx.num_groups > 1 else ()), Cn, H, W, dtype=torch.float32, device=dev)
         gd = _f32c(grad_depth)
         ga = _f32c(grad_alpha)
         bwd_tmp = torch.empty(int(lib.ogs_raster_backward_tmp_bytes(P)), dtype=torch.uint8, device=dev)
@@ -217,6 +228,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         b.debug = int(bool(rs.debug))
         b.num_rendered = int(ctx.num_rendered)
         b.geom_channels = int(ctx.geom_channels)
+        b.num_groups = int(ctx.num_groups)
         b.sorted_rec = ptr(sorted_rec)
         b.bg, b.means3D, b.colors_precomp, b.shs, b.opacities = ptr(bg), ptr(m3), ptr(cols), ptr(shs), ptr(opac)
         b.scales, b.rotations, b.cov3D_precomp = ptr(scl), ptr(rot), ptr(cov)
@@ -230,7 +242,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         check(lib.ogs_raster_backward(C.byref(b), _stream()), "ogs_raster_backward")
         if sink is not None:
             sink.append(g_sh_rgb)
-        return g_m3, g_m2, g_sh, g_col, g_op, g_scl, g_rot, g_cov, None, None, None
+        return g_m3, g_m2, g_sh, g_col, g_op, g_scl, g_rot, g_cov, None, None, None, None, None
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -257,6 +269,25 @@ def rasterize_fused(means3D, means2D, opacities, shs, extra_feats, raster_settin
                                      empty if scales is None else scales, empty if rotations is None else rotations,
                                      empty if cov3D_precomp is None else cov3D_precomp, raster_settings,
                                      3 if detach_extra_from_geometry else 0, sh_rgb_sink)
+
+
+def rasterize_groups(means3D, means2D, opacities, group_ids, num_groups, raster_settings, shs=None,
+                     colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None):
+    """Batched subset rendering: ONE pass returns, for every g in [0, num_groups), the
+    images the reference obtains by calling the rasterizer on the boolean-indexed subset ``group_ids == g``
+    (its per-cluster loops, gaussian_renderer/__init__.py:203-225,327-345): one preprocess, one sort and one
+    launch sequence instead of num_groups of each, and no index copies of the inputs.
+
+    Returns (color [G,C,H,W], radii [P], depth [G,1,H,W], alpha [G,1,H,W]); Gaussians whose id is outside
+    [0, num_groups) are not rendered (radii 0).  Gradients flow to the full-size inputs."""
+    empty = torch.Tensor([])
+    if (shs is None) == (colors_precomp is None):
+        raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+    return _RasterizeGaussians.apply(means3D, means2D, empty if shs is None else shs,
+                                     empty if colors_precomp is None else colors_precomp, opacities,
+                                     empty if scales is None else scales, empty if rotations is None else rotations,
+                                     empty if cov3D_precomp is None else cov3D_precomp, raster_settings, 0, None,
+                                     group_ids, int(num_groups))
 
 
 class GaussianRasterizer(nn.Module):

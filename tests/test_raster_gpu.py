@@ -194,7 +194,7 @@ def test_deferred_render_phase_and_capacity_overflow(gpu_device):
     W, H, f = 160, 96, 120.0
     sc, cam = helpers.tiny_scene(2500, W, H, f, seed=31)
     inp = helpers.oracle_inputs(sc, cam, use_sh=True)
-    key = (2500, W, H)
+    key = (2500, W, H, 1)
     R._LAST_NUM_RENDERED.pop(key, None)
     (c0, r0, d0, a0), _ = helpers.hip_forward(inp, cam, (0.1, 0.2, 0.3), 3, gpu_device, requires_grad=True)
     D = R._LAST_NUM_RENDERED[key]
@@ -332,3 +332,57 @@ def test_adversarial_scenes_forward_and_backward(gpu_device, kind, P, W, H):
         # long blending chains (thousands of fp32 T recoveries per pixel) loosen the bound a little
         tol = 5e-3 if kind == "long_lists" else GRAD_TOL
         assert np.abs(got - want).max() / scale < tol, (kind, k, np.abs(got - want).max() / scale)
+
+
+@pytest.mark.parametrize("use_sh,G", [(False, 5), (True, 3), (False, 37)])
+def test_grouped_pass_equals_subset_renders(gpu_device, use_sh, G):
+    """rasterize_groups (ONE pass, G images) == the reference's per-cluster loop of rasterizer calls on
+    boolean-indexed subsets (gaussian_renderer/__init__.py:203-225,327-345): forward bit for bit, gradients up to
+    the summation order of the float atomics."""
+    from opengaussian_amd.rasterizer import GaussianRasterizer, rasterize_groups
+    P, W, H, f = 4000, 150, 90, 110.0
+    sc, cam = helpers.tiny_scene(P, W, H, f, seed=21)
+    st = helpers.settings_for(cam, (0.2, 0.1, 0.3), 3, gpu_device)
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(-1, G, (P,), generator=g).to(gpu_device)           # -1: in no group
+    dev = lambda t: t.to(gpu_device).clone().requires_grad_(True)
+    names = ["means3D", "opacities", "scales", "rotations"] + (["shs"] if use_sh else ["ins_feat"])
+    Cn = 3 if use_sh else 6
+
+    def leaves():
+        return {n: dev(getattr(sc, n)) for n in names}
+
+    gC = torch.randn(G, Cn, H, W, generator=g).to(gpu_device)
+    gA = torch.randn(G, 1, H, W, generator=g).to(gpu_device)
+    gD = torch.randn(G, 1, H, W, generator=g).to(gpu_device)
+
+    A = leaves()
+    m2 = torch.zeros(P, 3, device=gpu_device, requires_grad=True)
+    color, radii, depth, alpha = rasterize_groups(
+        A["means3D"], m2, A["opacities"], ids, G, st, shs=A.get("shs"), colors_precomp=A.get("ins_feat"),
+        scales=A["scales"], rotations=A["rotations"])
+    assert color.shape == (G, Cn, H, W) and depth.shape == (G, 1, H, W) and alpha.shape == (G, 1, H, W)
+    torch.autograd.backward([color, depth, alpha], [gC, gD, gA])
+
+    B = leaves()
+    m2b = torch.zeros(P, 3, device=gpu_device, requires_grad=True)
+    rast = GaussianRasterizer(st)
+    assert int((radii[ids < 0] != 0).sum()) == 0
+    for gi in range(G):
+        mask = ids == gi
+        if int(mask.sum()) == 0:
+            # an empty subset: the reference skips the call; the grouped pass returns the background image
+            assert float(alpha[gi].abs().max()) == 0.0
+            continue
+        c, r, d, a = rast(means3D=B["means3D"][mask], means2D=m2b[mask], opacities=B["opacities"][mask],
+                          shs=B["shs"][mask] if use_sh else None,
+                          colors_precomp=None if use_sh else B["ins_feat"][mask], scales=B["scales"][mask],
+                          rotations=B["rotations"][mask])
+        assert torch.equal(c, color[gi]) and torch.equal(d, depth[gi]) and torch.equal(a, alpha[gi])
+        assert torch.equal(r, radii[mask])
+        torch.autograd.backward([c, d, a], [gC[gi], gD[gi], gA[gi]])
+    for n in names:
+        got, want = A[n].grad, B[n].grad
+        scale = float(want.abs().max()) + 1e-20
+        assert float((got - want).abs().max()) / scale < 2e-4, n
+    assert float((m2.grad - m2b.grad).abs().max()) / (float(m2b.grad.abs().max()) + 1e-20) < 2e-4
