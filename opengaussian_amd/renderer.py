@@ -21,7 +21,11 @@ import math
 
 import torch
 
-from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_fused
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_fused, rasterize_groups
+
+# a grouped pass materialises [G, C+2, H, W] fp32: bound G per pass (the loop over passes keeps the order)
+GROUPS_PER_PASS = 64
+BATCH_SUBSETS = True     # False: per-subset calls exactly as the reference loops (kept for the equivalence test)
 
 C0 = 0.28209479177387814
 C1 = 0.4886025119029199
@@ -57,6 +61,38 @@ def _knn_mean_filter(points: torch.Tensor) -> torch.Tensor:
     d2 = torch.cdist(points, points) ** 2
     knn = torch.topk(d2, K, dim=1, largest=False).values
     return knn.mean(dim=-1) < knn.mean() + knn.std()
+
+
+def _render_subsets(group_of_point: torch.Tensor, num_groups: int, min_points: int, raster_settings, means3D,
+                    means2D, opacity, scales, rotations, cov3D_precomp, colors=None, shs=None):
+    """Images of the subsets {p : group_of_point[p] == g} with at least `min_points` members, in ONE grouped
+    rasterizer pass per GROUPS_PER_PASS subsets instead of one boolean-indexed call each (the reference's
+    per-cluster loops, :203-225,327-345).  Returns (kept group numbers, colour list [C,H,W], alpha list [1,H,W])."""
+    valid = group_of_point >= 0
+    counts = torch.bincount(group_of_point[valid], minlength=num_groups)[:num_groups]
+    kept = torch.nonzero(counts >= min_points).flatten()
+    kept_list = kept.tolist()
+    imgs, sils = [], []
+    for c0 in range(0, len(kept_list), GROUPS_PER_PASS):
+        chunk = kept[c0:c0 + GROUPS_PER_PASS]
+        remap = torch.full((num_groups + 1,), -1, dtype=torch.int32, device=group_of_point.device)
+        remap[chunk] = torch.arange(chunk.numel(), dtype=torch.int32, device=group_of_point.device)
+        local = remap[torch.where(valid, group_of_point, torch.full_like(group_of_point, num_groups))]
+        if chunk.numel() == 1:
+            # a single subset: the plain pass on the indexed subset (what the reference does)
+            m = local == 0
+            color, _, _, alpha = GaussianRasterizer(raster_settings)(
+                means3D=means3D[m], means2D=means2D[m], shs=None if shs is None else shs[m],
+                colors_precomp=None if colors is None else colors[m], opacities=opacity[m],
+                scales=None if scales is None else scales[m], rotations=None if rotations is None else rotations[m],
+                cov3D_precomp=None if cov3D_precomp is None else cov3D_precomp[m])
+            imgs.append(color); sils.append(alpha)
+            continue
+        color, _, _, alpha = rasterize_groups(means3D, means2D, opacity, local, int(chunk.numel()), raster_settings,
+                                              shs=shs, colors_precomp=colors, scales=scales, rotations=rotations,
+                                              cov3D_precomp=cov3D_precomp)
+        imgs.extend(color.unbind(0)); sils.extend(alpha.unbind(0))
+    return kept_list, imgs, sils
 
 
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, iteration,
@@ -164,7 +200,23 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, iteration,
         rendered_clusters = []
         rendered_cluster_silhouettes = []
         scale_filter = (scales < 0.5).all(dim=1)
-        for idx in range(num_cluster):
+        if better_vis and BATCH_SUBSETS:
+            # every coarse cluster is rendered (:179-201): one grouped pass instead of num_cluster subset calls
+            gid = torch.where(viewed_pts & scale_filter, cluster_idx.to(torch.int64), torch.full_like(cluster_idx, -1, dtype=torch.int64))
+            if viewpoint_camera.bClusterOccur is not None:
+                occ = torch.as_tensor(viewpoint_camera.bClusterOccur).to(device=gid.device, dtype=torch.bool)
+                gid = torch.where(occ[gid.clamp_min(0)], gid, torch.full_like(gid, -1))
+            kept, imgs, sils = _render_subsets(gid, int(num_cluster), 100, raster_settings, means3D, means2D, opacity,
+                                               None if scales is None else scales * rescale_factor, rotations,
+                                               cov3D_precomp, colors=ins_feat)
+            if sils:
+                seen = (torch.stack([s_.max() for s_ in sils]) > 0.8).tolist()
+                for idx, img, sil, ok in zip(kept, imgs, sils, seen):
+                    if ok:
+                        cluster_occur[idx] = True
+                        rendered_clusters.append(img)
+                        rendered_cluster_silhouettes.append(sil)
+        for idx in ([] if (better_vis and BATCH_SUBSETS) else range(num_cluster)):
             if not better_vis and idx != selected_root_id:
                 continue
             if viewpoint_camera.bClusterOccur is not None and viewpoint_camera.bClusterOccur[idx] == False:  # noqa: E712
@@ -204,6 +256,30 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, iteration,
             lerf_range = range(start_leaf, end_leaf)
         else:
             lerf_range = selected_leaf_id.tolist()
+        root_seen = not (viewpoint_camera.bClusterOccur is not None and selected_root_id is not None and
+                         viewpoint_camera.bClusterOccur[selected_root_id] == False)  # noqa: E712
+        batched = BATCH_SUBSETS and selected_leaf_id is None and not post_process
+        if batched and root_seen and not (viewpoint_camera.bClusterOccur is not None and selected_root_id is None):
+            # all leaves of the range in grouped passes (:245-356 without the per-leaf Python loop)
+            n_leaf = end_leaf - start_leaf
+            lid = leaf_cluster_idx.to(torch.int64) - start_leaf
+            ok_pt = (lid >= 0) & (lid < n_leaf) & viewed_pts
+            if pre_mask is not None:
+                ok_pt = ok_pt & pre_mask
+            if better_vis:
+                ok_pt = ok_pt & scale_filter
+            gid = torch.where(ok_pt, lid, torch.full_like(lid, -1))
+            min_pts = 100 if better_vis else 10
+            kept, imgs, sils = _render_subsets(gid, n_leaf, min_pts, raster_settings, means3D, means2D, opacity, scales,
+                                               rotations, cov3D_precomp, colors=None if seg_rgb else ins_feat,
+                                               shs=shs if seg_rgb else None)
+            for k_, img, sil in zip(kept, imgs, sils):
+                occured_leaf_id.append(start_leaf + k_)
+                if seg_rgb and ins_feat.shape[-1] > 3:
+                    img = torch.cat((img, img), dim=0)
+                rendered_leaf_clusters.append(img)
+                rendered_leaf_cluster_silhouettes.append(sil)
+            lerf_range = []
         for _, leaf_idx in enumerate(lerf_range):
             if viewpoint_camera.bClusterOccur is not None and viewpoint_camera.bClusterOccur[selected_root_id] == False:  # noqa: E712
                 continue

@@ -133,3 +133,64 @@ def test_render_post_process_and_leaf_path(gpu_device):
     assert out["occured_leaf_id"] == [1] and len(out["leaf_clusters_imgs"]) == 1
     assert out["leaf_clusters_imgs"][0].shape == (6, H, W) and out["leaf_cluster_silhouettes"].shape == (1, H, W)
     assert out["render"].shape == (3, H, W) and float(out["render"].max()) > 0
+
+
+@pytest.mark.parametrize("mode", ["leaf_range", "leaf_seg_rgb", "coarse_better_vis", "leaf_all_premask"])
+def test_batched_cluster_loops_equal_per_subset_calls(gpu_device, mode):
+    """render()'s coarse / fine cluster loops through grouped rasterizer passes == the reference's one call per
+    boolean-indexed subset (gaussian_renderer/__init__.py:179-236,245-356): same kept ids, identical images."""
+    from opengaussian_amd import renderer as R
+    dev = gpu_device
+    W, H, f = 112, 80, 90.0
+    P = 6000
+    sc, cam = helpers.tiny_scene(P, W, H, f, seed=31, log_scale_mean=-3.5)
+    cam = cam.to(dev)
+    pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=False)
+    root_num, leaf_num = 4, 5
+    g = torch.Generator().manual_seed(2)
+    leaf_idx = torch.randint(0, root_num * leaf_num, (P,), generator=g).to(dev)
+    leaf_idx[leaf_idx == 7] = 6                       # leaf 7 empty, leaf 13 almost empty (< 10 points)
+    few = torch.nonzero(leaf_idx == 13).flatten()
+    leaf_idx[few[5:]] = 12
+    cluster_idx = leaf_idx // leaf_num
+    kw = dict(iteration=1, rescale=False, render_feat_map=False, root_num=root_num, leaf_num=leaf_num)
+    if mode == "leaf_range":
+        kw.update(leaf_cluster_idx=leaf_idx, selected_root_id=2)
+    elif mode == "leaf_seg_rgb":
+        kw.update(leaf_cluster_idx=leaf_idx, selected_root_id=1, seg_rgb=True)
+    elif mode == "leaf_all_premask":
+        kw.update(leaf_cluster_idx=leaf_idx, pre_mask=(torch.arange(P, device=dev) % 3 != 0))
+    else:
+        kw.update(cluster_idx=cluster_idx, render_cluster=True, better_vis=True)
+    outs = []
+    for batch in (True, False):
+        R.BATCH_SUBSETS = batch
+        old = R.GROUPS_PER_PASS
+        R.GROUPS_PER_PASS = 6                         # several passes + a single-subset tail in "leaf_all_premask"
+        try:
+            pc = FakeGaussians(sc, dev)
+            out = R.render(cam, pc, pipe, torch.tensor([0.1, 0.0, 0.2], device=dev), **kw)
+            key_img = "cluster_imgs" if mode == "coarse_better_vis" else "leaf_clusters_imgs"
+            key_sil = "cluster_silhouettes" if mode == "coarse_better_vis" else "leaf_cluster_silhouettes"
+            loss = sum((im * (i + 1)).sum() for i, im in enumerate(out[key_img])) + out[key_sil].sum()
+            loss.backward()
+            outs.append((out, pc, key_img, key_sil))
+        finally:
+            R.BATCH_SUBSETS = True
+            R.GROUPS_PER_PASS = old
+    (a, pa, ki, ks), (b, pb, _, _) = outs
+    assert len(a[ki]) == len(b[ki]) and len(a[ki]) >= 2
+    if mode != "coarse_better_vis":
+        assert a["occured_leaf_id"] == b["occured_leaf_id"]
+        assert 7 not in a["occured_leaf_id"] and 13 not in a["occured_leaf_id"]
+    else:
+        assert torch.equal(a["cluster_occur"], b["cluster_occur"])
+    for x, y in zip(a[ki], b[ki]):
+        assert x.shape == y.shape and torch.equal(x, y)
+    assert torch.equal(a[ks], b[ks])
+    for la, lb, name in zip(pa.leaves(), pb.leaves(), ("xyz", "scaling", "rotation", "opacity", "features", "ins_feat")):
+        if lb.grad is None:
+            assert la.grad is None or float(la.grad.abs().max()) == 0.0, name
+            continue
+        scale = float(lb.grad.abs().max()) + 1e-20
+        assert float((la.grad - lb.grad).abs().max()) / scale < 5e-4, name
