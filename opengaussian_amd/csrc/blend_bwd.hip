@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
                 }
             }
             {
-                const float diff = cur[7] - Rd;
+                const float diff = rec_j.feat(C) - Rd;
                 dL_dalpha += diff * gd;
                 Rd += al * diff;
             }
@@ -214,19 +214,23 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
             const float y = wave_fold16(v);
             const int slot = lane >> 2;
             if ((lane & 3) == 0 && slot < C + 7) {
-                const uint32_t gid = __float_as_uint(rec_j.feat(C));
+                const uint32_t gid = __float_as_uint(cur[7]);
                 atomicAdd(grad_rec + (size_t)gid * GS + slot, y);
             }
         }
     };
     StreamRec<C> recA, recB;
     recA.load(base + (size_t)(hi - 1) * RS);
+    // `p` = lowest address the iteration loads from (entry idx-2), so both records are reached with non-negative
+    // immediate s_load offsets (see blend_fwd.hip); it may run into the front pad / the previous tile: those
+    // records are loaded but never consumed
+    const float* __restrict__ p = base + ((ptrdiff_t)hi - 3) * RS;      // wave-uniform -> scalar loads
     for (int idx = hi - 1; idx >= 0; idx -= 2) {
-        const float* __restrict__ r = base + (size_t)idx * RS;     // wave-uniform -> scalar loads
-        recB.load(r - RS);
+        recB.load(p + RS);
         consume(recA, idx);
-        recA.load(r - 2 * RS);            // may touch the front pad / the previous tile: never consumed
+        recA.load(p);
         if (idx > 0) consume(recB, idx - 1);
+        p -= 2 * RS;
     }
 }
 

@@ -27,6 +27,7 @@ namespace {
 
 constexpr float kAlphaMin = 1.0f / 255.0f;
 constexpr float kThrMargin = 0.01f;
+typedef float v2f __attribute__((ext_vector_type(2)));   // register pair -> v_pk_fma_f32
 
 // max over the box d in [xlo,xhi] x [ylo,yhi] of  -0.5*(A dx^2 + C dy^2) - B dx dy   (A, C > 0, AC - B^2 > 0)
 __device__ __forceinline__ float max_power_in_box(float A, float B, float Cc, float xlo, float xhi, float ylo,
@@ -48,8 +49,10 @@ __device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d) {
 }
 
 // stream record (per kept (entry, quadrant) pair):
-//   [0] x  [1] y  [2] -0.5*A  [3] -B  [4] -0.5*C  [5] h=-thr/2  [6] opacity  [7] depth  [8..8+C) features
-//   [8+C] Gaussian id (bit pattern), rest zero padding to a multiple of 4 floats
+//   [0] x  [1] y  [2] -0.5*A  [3] -B  [4] -0.5*C  [5] h=-thr/2  [6] opacity  [7] Gaussian id (bit pattern)
+//   [8..8+C) features  [8+C] view depth, rest zero padding to a multiple of 4 floats.
+// The depth sits right behind the features so that the (feature, feature) / (feature, depth) operand pairs of
+// the blend loops' packed FMAs are even-aligned SGPR pairs straight out of s_load (no s_mov shuffles).
 template <int C>
 __global__ __launch_bounds__(kBlock) void pack_sorted_kernel(const uint2* __restrict__ ranges,
                                                              const uint32_t* __restrict__ point_list, int gx,
@@ -75,8 +78,10 @@ __global__ __launch_bounds__(kBlock) void pack_sorted_kernel(const uint2* __rest
 #pragma unroll
         for (int k = 0; k < (SV - 2) * 4; ++k) f[k] = 0.f;
         float h = 0.f;
+        uint32_t gid_of_thread = 0;
         if (i < n) {
             const uint32_t gid = point_list[range.x + i];
+            gid_of_thread = gid;
             const float4* src = rec + (size_t)gid * NV;
             a = src[0]; b = src[1];
 #pragma unroll
@@ -84,7 +89,7 @@ __global__ __launch_bounds__(kBlock) void pack_sorted_kernel(const uint2* __rest
                 const float4 t = src[2 + v];
                 f[4 * v] = t.x; f[4 * v + 1] = t.y; f[4 * v + 2] = t.z; f[4 * v + 3] = t.w;
             }
-            f[C] = __uint_as_float(gid);
+            f[C] = a.z;                          // view depth rides next to the features (slot C)
             // candidate window thr <= power <= 0, thr = ln(1/(255*opacity)) - margin; stored as h = -thr/2 so the
             // blend loops test it with ONE compare |power + h| <= h (opacity <= 0: NaN/-inf, never a candidate)
             h = 0.5f * (__logf(255.0f * b.w) + kThrMargin);
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(kBlock) void pack_sorted_kernel(const uint2* __rest
         const uint64_t pos = before + inc - mine;          // exclusive position inside this chunk, per quadrant
         if (mask) {
             const float4 r0 = make_float4(a.x, a.y, -0.5f * b.x, -b.y);
-            const float4 r1 = make_float4(-0.5f * b.z, h, b.w, a.z);
+            const float4 r1 = make_float4(-0.5f * b.z, h, b.w, __uint_as_float(gid_of_thread));
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (mask & (1u << q)) {
@@ -173,10 +178,12 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
     //     so "current = next" costs no register moves.
     float fxe = inside ? fx : kFar;
     float T = 1.0f;
-    float acc[C];
+    // accumulators of (feature 0..C-1, depth) as register pairs: one v_pk_fma_f32 per pair and entry
+    constexpr int NPF = (C + 2) / 2;
+    v2f accp[NPF];
 #pragma unroll
-    for (int c = 0; c < C; ++c) acc[c] = 0.f;
-    float dacc = 0.f, wacc = 0.f;
+    for (int k = 0; k < NPF; ++k) accp[k] = (v2f){0.f, 0.f};
+    float wacc = 0.f;
     uint32_t last = 0;
     bool all_done = false;
 
@@ -193,9 +200,9 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
                 const float test_T = T * (1.0f - alpha);
                 stop = test_T < 0.0001f;                       // this entry is NOT applied (A.3)
                 const float w = stop ? 0.f : alpha * T;
+                const v2f w2 = {w, w};
 #pragma unroll
-                for (int c = 0; c < C; ++c) acc[c] += rec_j.feat(c) * w;
-                dacc += cur[7] * w;
+                for (int k = 0; k < NPF; ++k) accp[k] += (v2f){rec_j.feat(2 * k), rec_j.feat(2 * k + 1)} * w2;
                 wacc += w;
                 T = stop ? T : test_T;
                 last = w > 0.f ? (uint32_t)j + 1u : last;
@@ -208,12 +215,16 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
     // regions are contiguous, so prefetching up to two records past the end needs no bounds test
     StreamRec<C> recA, recB;
     recA.load(base);
+    // `p` always points at the LOWEST address the iteration loads from, so that both records are reached with
+    // non-negative immediate offsets of s_load (gfx9-family SMEM offsets are unsigned; a pointer that runs ahead
+    // costs an s_add_u32/s_addc_u32 pair per load)
+    const float* __restrict__ p = base + RS;
     for (int j = 0; j < n && !all_done; j += 2) {
-        const float* __restrict__ r = base + (size_t)j * RS;
-        recB.load(r + RS);
+        recB.load(p);
         consume(recA, j);
-        recA.load(r + 2 * RS);
+        recA.load(p + RS);
         if (j + 1 < n) consume(recB, j + 1);
+        p += 2 * RS;
     }
 
     if (inside) {
@@ -221,8 +232,8 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
         const size_t pix = (size_t)img * plane + (size_t)py * W + px;       // pixel of image `img`
         float* oc = out_color + (size_t)img * (C - 1) * plane;               // + pix: image stride is C planes
 #pragma unroll
-        for (int c = 0; c < C; ++c) oc[c * plane + pix] = acc[c] + T * bg[c];
-        out_depth[pix] = dacc;
+        for (int c = 0; c < C; ++c) oc[c * plane + pix] = ((c & 1) ? accp[c / 2].y : accp[c / 2].x) + T * bg[c];
+        out_depth[pix] = (C & 1) ? accp[C / 2].y : accp[C / 2].x;
         out_alpha[pix] = wacc;
         n_contrib[pix] = last;          // index into the QUADRANT stream (+1); see export_n_contrib_kernel
     }
@@ -252,7 +263,7 @@ __global__ __launch_bounds__(kBlock) void export_n_contrib_kernel(const uint2* _
     uint32_t res = 0;
     if (last > 0) {
         const float* r = stream + ((size_t)range.x * 4 + (size_t)wave * n_tile + (last - 1)) * RS;
-        const uint32_t gid = __float_as_uint(r[8 + C]);
+        const uint32_t gid = __float_as_uint(r[7]);
         for (int i = 0; i < n_tile; ++i)
             if (point_list[range.x + i] == gid) { res = (uint32_t)i + 1u; break; }
     }

@@ -85,7 +85,7 @@ struct Carver {
 __host__ __device__ constexpr int rec_vec4(int C) { return 2 + (C + 3) / 4; }   // float4 per record
 
 // Per sorted-list-entry stream record read by the blend kernels through the scalar path (blend_fwd.hip):
-// 8 geometry floats + C features + Gaussian id, padded to float4.
+// 8 geometry floats (the last is the Gaussian id) + C features + depth, padded to float4.
 __host__ __device__ constexpr int stream_vec4(int C) { return (8 + C + 1 + 3) / 4; }
 
 // The stream buffer carries two unused records in front of entry 0 (one is skipped by stream_base... the
@@ -105,8 +105,8 @@ typedef float f8 __attribute__((ext_vector_type(8)));
 template <int C>
 struct StreamRec {
     static constexpr int NF4 = stream_vec4(C) - 2;
-    f8 g;               // x, y, -A/2, -B, -C/2, thr, opacity, depth
-    float4 f[NF4];      // features, then the Gaussian id bit pattern at slot C
+    f8 g;               // x, y, -A/2, -B, -C/2, h = -thr/2, opacity, Gaussian id (bit pattern)
+    float4 f[NF4];      // features, then the view depth at slot C
     __device__ __forceinline__ void load(const float* __restrict__ p) {
         g = *reinterpret_cast<const f8*>(p);
 #pragma unroll
