@@ -126,6 +126,9 @@ constexpr int kFlatScanBlocks = 16384;   // up to 33.5 M elements scan in two la
 // ---- radix pass -----------------------------------------------------------------------------------
 // n_dev (optional): the element count lives in device memory (deferred render phase: the host sized the launch
 // for a capacity n_cap and has not read the true count back yet); workgroups past the true count see no elements.
+// ITEMS keys per thread: 16 for the long (Gaussian, tile) lists; 4 for the P-sized depth sort, whose 16-key
+// version is only ~1 workgroup per CU and therefore latency-bound (19 us per 8 MB pass).
+template <int ITEMS>
 __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const uint32_t* __restrict__ keys, int64_t n_cap,
                                                             const uint32_t* __restrict__ n_dev, int shift,
                                                             int bits, uint32_t* __restrict__ hist, int nblocks) {
@@ -135,9 +138,9 @@ __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const uint32_t* __re
     const uint32_t mask = ndig - 1;
     h[threadIdx.x] = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * kSortTile;
+    const int64_t base = (int64_t)blockIdx.x * (kBlock * ITEMS);
 #pragma unroll
-    for (int i = 0; i < kSortItems; ++i) {
+    for (int i = 0; i < ITEMS; ++i) {
         const int64_t idx = base + i * kBlock + threadIdx.x;
         if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & mask], 1u);
     }
@@ -176,6 +179,7 @@ __global__ __launch_bounds__(kBlock) void radix_rowscan_kernel(uint32_t* __restr
     if (threadIdx.x == 0) row_total[blockIdx.x] = carry;
 }
 
+template <int ITEMS>
 __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                                const uint32_t* __restrict__ vals_in,
                                                                uint32_t* __restrict__ keys_out,
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint32_t* _
     __shared__ uint32_t wave_hist_s[kBlock / kWave][256];
     __shared__ uint32_t scan_sums[4];
     __shared__ uint32_t dig_start[256], glob_base[256];
-    __shared__ uint32_t stage_k[kSortTile], stage_v[kSortTile];
+    __shared__ uint32_t stage_k[kBlock * ITEMS], stage_v[kBlock * ITEMS];
     volatile uint32_t(*wave_hist)[256] = wave_hist_s;
     const int64_t n = n_dev ? min((int64_t)*n_dev, n_cap) : n_cap;
     const int ndig = 1 << bits;
@@ -197,12 +201,12 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint32_t* _
     for (int w = 0; w < kBlock / kWave; ++w) wave_hist_s[w][tid] = 0;
     __syncthreads();
 
-    // each wave owns a contiguous run of kSortItems*64 keys; item i = 64 consecutive keys, so
+    // each wave owns a contiguous run of ITEMS*64 keys; item i = 64 consecutive keys, so
     // (wave, item, lane) order == memory order, which is what stability needs.
-    const int64_t base = (int64_t)blockIdx.x * kSortTile + (int64_t)wave * (kSortItems * kWave);
-    uint32_t key[kSortItems], val[kSortItems], rank[kSortItems];
+    const int64_t base = (int64_t)blockIdx.x * (kBlock * ITEMS) + (int64_t)wave * (ITEMS * kWave);
+    uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
 #pragma unroll
-    for (int i = 0; i < kSortItems; ++i) {
+    for (int i = 0; i < ITEMS; ++i) {
         const int64_t idx = base + i * kWave + lane;
         const bool valid = idx < n;
         key[i] = valid ? keys_in[idx] : 0xFFFFFFFFu;
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint32_t* _
     }
     const uint64_t lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
-    for (int i = 0; i < kSortItems; ++i) {
+    for (int i = 0; i < ITEMS; ++i) {
         const int64_t idx = base + i * kWave + lane;
         const bool valid = idx < n;
         const uint32_t d = (key[i] >> shift) & mask;
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint32_t* _
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < kSortItems; ++i) {
+    for (int i = 0; i < ITEMS; ++i) {
         const int64_t idx = base + i * kWave + lane;
         if (idx < n) {
             const uint32_t d = (key[i] >> shift) & mask;
@@ -319,7 +323,7 @@ size_t scan_tmp_bytes(int64_t n) {
 }
 
 size_t sort_tmp_bytes(int64_t n) {
-    const int64_t hist = (int64_t)256 * sort_blocks(n > 0 ? n : 1);
+    const int64_t hist = (int64_t)256 * sort_blocks_for(n > 0 ? n : 1);
     // histogram table + 256 row totals; the tail is also what exclusive_scan_u32 callers borrow as scan scratch
     return align_up((size_t)hist * sizeof(uint32_t)) + align_up(256 * sizeof(uint32_t)) + scan_tmp_bytes(hist);
 }
@@ -367,16 +371,26 @@ int radix_pass(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_
                int shift, int bits, void* tmp, hipStream_t stream, int debug, const uint32_t* n_dev) {
     if (n <= 0) return OGS_OK;
     if (bits < 1 || bits > 8) { set_error("radix_pass: bits=%d out of range", bits); return OGS_ERR_INVALID_ARG; }
-    const int nb = sort_blocks(n);
+    const int items = sort_items_for(n);
+    const int nb = sort_blocks_for(n);
     const int ndig = 1 << bits;
     uint32_t* hist = static_cast<uint32_t*>(tmp);
     uint32_t* row_total = reinterpret_cast<uint32_t*>(static_cast<char*>(tmp) + align_up((size_t)256 * nb * sizeof(uint32_t)));
-    OGS_LAUNCH(radix_hist_kernel, dim3(nb), dim3(kBlock), 0, stream, keys_in, n, n_dev, shift, bits, hist, nb);
+    if (items == 4) {
+        OGS_LAUNCH(radix_hist_kernel<4>, dim3(nb), dim3(kBlock), 0, stream, keys_in, n, n_dev, shift, bits, hist, nb);
+    } else {
+        OGS_LAUNCH(radix_hist_kernel<16>, dim3(nb), dim3(kBlock), 0, stream, keys_in, n, n_dev, shift, bits, hist, nb);
+    }
     OGS_LAUNCH_CHECK(debug, stream);
     OGS_LAUNCH(radix_rowscan_kernel, dim3(ndig), dim3(kBlock), 0, stream, hist, nb, row_total);
     OGS_LAUNCH_CHECK(debug, stream);
-    OGS_LAUNCH(radix_scatter_kernel, dim3(nb), dim3(kBlock), 0, stream, keys_in, vals_in, keys_out, vals_out, n, n_dev,
-                       shift, bits, (const uint32_t*)hist, (const uint32_t*)row_total, nb);
+    if (items == 4) {
+        OGS_LAUNCH(radix_scatter_kernel<4>, dim3(nb), dim3(kBlock), 0, stream, keys_in, vals_in, keys_out, vals_out, n, n_dev,
+                   shift, bits, (const uint32_t*)hist, (const uint32_t*)row_total, nb);
+    } else {
+        OGS_LAUNCH(radix_scatter_kernel<16>, dim3(nb), dim3(kBlock), 0, stream, keys_in, vals_in, keys_out, vals_out, n, n_dev,
+                   shift, bits, (const uint32_t*)hist, (const uint32_t*)row_total, nb);
+    }
     OGS_LAUNCH_CHECK(debug, stream);
     return OGS_OK;
 }

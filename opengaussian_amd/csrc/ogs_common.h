@@ -168,9 +168,13 @@ struct ImageState {     // kept until backward
 int launch_export_n_contrib(const OgsRasterFwdArgs& a, const ImageState& is, uint32_t* out, hipStream_t s);
 
 // radix sort / scan (binning.hip) ---------------------------------------------------------------
-constexpr int kSortItems = 16;                         // keys per thread
-constexpr int kSortTile = kBlock * kSortItems;         // 4096 keys per workgroup
-inline int sort_blocks(int64_t n) { return (int)((n + kSortTile - 1) / kSortTile); }
+// keys per thread of a radix pass: 16 (4096-key workgroups) for long lists, 4 for short ones so that a P-sized
+// sort still spreads over several workgroups per CU
+inline int sort_items_for(int64_t n) { return n <= (int64_t)(3 << 20) ? 4 : 16; }
+inline int sort_blocks_for(int64_t n) {
+    const int64_t tile = (int64_t)kBlock * sort_items_for(n);
+    return (int)((n + tile - 1) / tile);
+}
 size_t scan_tmp_bytes(int64_t n);
 size_t sort_tmp_bytes(int64_t n);                      // histogram + scan scratch for one pass
 
