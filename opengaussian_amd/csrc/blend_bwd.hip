@@ -80,7 +80,9 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 
 // GC = geom_channels as a compile-time constant (C: every channel feeds geometry; 3: fused RGB + detached
 // features): a runtime value turned every per-channel update into v_cndmask selects and kept dead math alive.
-template <int C, int GC>
+// DEPTH = false: no gradient arrives through the depth image (dL_ddepth == NULL -- every loss of the reference,
+// gaussian_renderer/__init__.py:362 "not used"): the depth recursion and its dL/dalpha term are compiled out.
+template <int C, int GC, bool DEPTH>
 __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     const uint2* __restrict__ ranges, const float* __restrict__ stream, int W, int H, int gx, int tiles,
     const float* __restrict__ bg, const float* __restrict__ out_alpha, const uint32_t* __restrict__ n_contrib,
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
         g[c] = inside ? dL_dcolor[c * plane + pix] : 0.f;
         if (c < GC) bg_dot += bg[c] * g[c];
     }
-    const float gd = (inside && dL_ddepth) ? dL_ddepth[pix] : 0.f;
+    const float gd = (DEPTH && inside) ? dL_ddepth[pix] : 0.f;
     const float ga = (inside && dL_dalpha_map) ? dL_dalpha_map[pix] : 0.f;
     // (dL/dpixel_0 .. dL/dpixel_{C-1}, dL/ddepth) as register pairs for v_pk_mul_f32
     constexpr int NP = (C + 2) / 2;
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
                     R[c] += al * diff;
                 }
             }
-            {
+            if constexpr (DEPTH) {
                 const float diff = rec_j.feat(C) - Rd;
                 dL_dalpha += diff * gd;
                 Rd += al * diff;
@@ -249,18 +251,20 @@ int launch_c(const OgsRasterBwdArgs& a, const ImageState& is, float* grad_rec, h
                                                     "blend_backward_kernel<9>", "blend_backward_kernel<12>"};
     const float* stream = (const float*)stream_base<C>(const_cast<void*>(a.sorted_rec));
     const unsigned vtiles = (unsigned)(gx * gy) * (unsigned)num_groups_of(a.num_groups);
+#define OGS_BWD_LAUNCH(GCV, DEPTHV)                                                                                  \
+    OGS_LAUNCH_NAMED(chan_name<C>(kNames), (blend_backward_kernel<C, GCV, DEPTHV>), dim3(vtiles), dim3(kBlock), 0, s,   \
+                     (const uint2*)is.ranges, stream, a.W, a.H, gx, gx * gy, a.bg, a.out_alpha,                         \
+                     (const uint32_t*)is.n_contrib, a.dL_dcolor, a.dL_ddepth, a.dL_dalpha, grad_rec)
+    const bool depth = a.dL_ddepth != nullptr;
     if (a.geom_channels <= 0 || a.geom_channels >= C) {
-        OGS_LAUNCH_NAMED(chan_name<C>(kNames), (blend_backward_kernel<C, C>), dim3(vtiles), dim3(kBlock), 0, s,
-                         (const uint2*)is.ranges, stream, a.W, a.H, gx, gx * gy, a.bg, a.out_alpha, (const uint32_t*)is.n_contrib,
-                         a.dL_dcolor, a.dL_ddepth, a.dL_dalpha, grad_rec);
+        if (depth) OGS_BWD_LAUNCH(C, true); else OGS_BWD_LAUNCH(C, false);
     } else if (a.geom_channels == 3) {
-        OGS_LAUNCH_NAMED(chan_name<C>(kNames), (blend_backward_kernel<C, 3>), dim3(vtiles), dim3(kBlock), 0, s,
-                         (const uint2*)is.ranges, stream, a.W, a.H, gx, gx * gy, a.bg, a.out_alpha, (const uint32_t*)is.n_contrib,
-                         a.dL_dcolor, a.dL_ddepth, a.dL_dalpha, grad_rec);
+        if (depth) OGS_BWD_LAUNCH(3, true); else OGS_BWD_LAUNCH(3, false);
     } else {
         set_error("backward: geom_channels must be 0, 3 or C (got %d with C=%d)", a.geom_channels, C);
         return OGS_ERR_UNSUPPORTED;
     }
+#undef OGS_BWD_LAUNCH
     OGS_LAUNCH_CHECK(a.debug, s);
     return OGS_OK;
 }

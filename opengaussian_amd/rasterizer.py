@@ -43,6 +43,19 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool
 
 
+_READBACK: dict = {}
+
+
+def _readback_slot(dev):
+    """One pinned int32 + one event per device, reused by every pass: the forward waits for the copy before it
+    returns, so two passes never have a read-back in flight at the same time (pinned allocations are slow)."""
+    slot = _READBACK.get(dev)
+    if slot is None:
+        slot = (torch.empty(1, dtype=torch.int32, pin_memory=True), torch.cuda.Event())
+        _READBACK[dev] = slot
+    return slot
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -67,6 +80,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = raster_settings
         ctx.geom_channels = int(geom_channels)
         ctx.sh_rgb_sink = sh_rgb_sink
+        # outputs no loss touches (depth in every reference loss, alpha without RGBA data) must reach backward as
+        # None, not as zero images: the kernels compile the corresponding terms out
+        ctx.set_materialize_grads(False)
         G = max(int(num_groups), 1)
         ctx.num_groups = G
         if G > 1:
@@ -164,10 +180,9 @@ class _RasterizeGaussians(torch.autograd.Function):
             # pass at this size; the true count arrives through an async pinned copy and is only WAITED for after
             # everything is queued.  Overflow (scene changed a lot) -> redo the render phase with exact buffers.
             check(lib.ogs_raster_forward_geometry(C.byref(a), stream, None), "ogs_raster_forward_geometry")
-            pinned = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            pinned, ev = _readback_slot(dev)
             check(lib.ogs_raster_read_num_rendered_async(C.byref(a), stream, pinned.data_ptr()),
                   "ogs_raster_read_num_rendered_async")
-            ev = torch.cuda.Event()
             ev.record()
             cap = int(last * 1.25) + 4096
             point_list, bin_tmp, sorted_rec = alloc_render(cap)
