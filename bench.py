@@ -363,7 +363,8 @@ def main():
         dom_bytes = ab.get(dom_base)
         traffic = None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_file):
+        # the committed counter table was collected on the default workload (S1M-1080p, fused pass)
+        if os.path.exists(pmc_file) and args.workload == "S1M-1080p" and fused:
             try:
                 traffic = json.load(open(pmc_file)).get(dom)
             except Exception:
