@@ -45,6 +45,11 @@ class OgsRasterBwdArgs(C.Structure):
     ]
 
 
+class OgsAdamTensor(C.Structure):
+    _fields_ = [("param", _vp), ("grad", _vp), ("exp_avg", _vp), ("exp_avg_sq", _vp), ("numel", C.c_int64),
+                ("lr", C.c_double), ("step", C.c_int64)]
+
+
 # name -> (restype, argtypes); also the list the symbol-export test checks against the headers
 SIGNATURES = {
     "ogs_version": (C.c_int, []),
@@ -75,6 +80,7 @@ SIGNATURES = {
     "ogs_mask_feature_sums_backward": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int64, _vp, _vp]),
     "ogs_mask_cohesion": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int64, _vp, _vp]),
     "ogs_mask_cohesion_backward": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int64, _vp, _vp, _vp]),
+    "ogs_adam_step": (C.c_int, [C.POINTER(OgsAdamTensor), C.c_int32, C.c_double, C.c_double, C.c_double, _vp]),
     "ogs_kmeans_accumulate": (C.c_int, [_vp, C.c_int64, C.c_int32, _vp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
     "ogs_kmeans_update": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp]),
     "ogs_kmeans_gather": (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, C.c_int32, _vp, _vp]),

@@ -25,6 +25,7 @@ EXTRA = {
     "preprocess_fwd.hip": ["-ffp-contract=off"],
     # k-means argmin: same sum-of-squares operation order as oracle/kmeans_oracle.py (HBM-bound, FMA buys nothing)
     "kmeans.hip": ["-ffp-contract=off"],
+    "adam.hip": ["-ffp-contract=off"],
 }
 
 
