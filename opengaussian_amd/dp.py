@@ -106,6 +106,7 @@ class ShGradExchange:
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         self.gathered = torch.zeros(self.world, self.P, 3, dtype=torch.float32, device=device)
+        self.local = torch.zeros(self.P, 3, dtype=torch.float32, device=device)     # send buffer (not aliased)
         self._work = None
         self._stream = torch.cuda.Stream(device) if torch.device(device).type == "cuda" else None
 
@@ -114,7 +115,7 @@ class ShGradExchange:
         if self.world == 1:
             self.gathered[0].copy_(dL_drgb)
             return
-        local = self.gathered[self.rank]
+        local = self.local
         local.copy_(dL_drgb)
 
         def issue():
