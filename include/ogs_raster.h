@@ -79,8 +79,10 @@ typedef struct OgsRasterFwdArgs {
     void* image_buffer;          /* ogs_raster_image_bytes(W, H): kept until backward */
     uint32_t* point_list;        /* [num_rendered] sorted Gaussian ids: kept until backward (render phase) */
     void* binning_tmp;           /* ogs_raster_binning_tmp_bytes(num_rendered, W, H) (render phase) */
-    void* sorted_rec;            /* ogs_raster_sorted_bytes(num_rendered, C): packed per-tile record stream the
-                                    blend kernels read through the scalar path; kept until backward */
+    void* sorted_rec;            /* ogs_raster_sorted_bytes(num_rendered, C): one packed record per sorted-list entry,
+                                    read by the blend kernels through the scalar path; kept until backward */
+    void* quad_list;             /* ogs_raster_quad_list_bytes(num_rendered): per (tile, 8x8 quadrant) the tile-local
+                                    indices of the entries that can reach the quadrant; kept until backward */
     /* Grouped pass ("batched subset rendering via a per-Gaussian group_id"): with
      * num_groups = G > 1 the pass renders G independent images in one go -- image g blends exactly the
      * Gaussians with group_ids[p] == g, i.e. what G separate calls on the boolean-indexed subsets
@@ -126,6 +128,7 @@ typedef struct OgsRasterBwdArgs {
     const void* image_buffer;
     const uint32_t* point_list;
     const void* sorted_rec;      /* from forward */
+    const void* quad_list;       /* from forward */
     void* bwd_tmp;               /* ogs_raster_backward_tmp_bytes(P): zeroed by the call */
     float* dL_dmeans2D;          /* [P,3] (x,y in NDC units: pixel gradient * 0.5*W / 0.5*H; z = 0) */
     float* dL_dcolors;           /* same shape as colors_precomp: [P,C], or [P,C-3] in a fused SH pass */
@@ -154,6 +157,7 @@ size_t ogs_raster_image_bytes_grouped(int32_t W, int32_t H, int32_t num_groups);
 size_t ogs_raster_binning_tmp_bytes(int64_t num_rendered, int32_t W, int32_t H);
 size_t ogs_raster_backward_tmp_bytes(int32_t P);
 size_t ogs_raster_sorted_bytes(int64_t num_rendered, int32_t C);
+size_t ogs_raster_quad_list_bytes(int64_t num_rendered);
 
 /* Phase 1: fills radii + geom_buffer, leaves the depth order and tile offsets in geom_tmp, writes
  * num_rendered to *num_rendered_host (host memory) and returns after the stream has finished it
@@ -161,7 +165,7 @@ size_t ogs_raster_sorted_bytes(int64_t num_rendered, int32_t C);
  * num_rendered_host == NULL: no read-back, no synchronisation (see the deferred variant below). */
 int ogs_raster_forward_geometry(const OgsRasterFwdArgs* args, void* stream, int64_t* num_rendered_host);
 
-/* Phase 2: needs args->point_list / args->binning_tmp / args->sorted_rec sized for num_rendered.  Asynchronous. */
+/* Phase 2: needs args->point_list / binning_tmp / sorted_rec / quad_list sized for num_rendered.  Asynchronous. */
 int ogs_raster_forward_render(const OgsRasterFwdArgs* args, int64_t num_rendered, void* stream);
 
 /* Sync-free variant of the two calls above (removes the GPU idle gap of the read-back):

@@ -25,7 +25,7 @@ class OgsRasterFwdArgs(C.Structure):
         ("viewmatrix", _vp), ("projmatrix", _vp), ("campos", _vp),
         ("out_color", _vp), ("out_depth", _vp), ("out_alpha", _vp), ("radii", _vp),
         ("geom_buffer", _vp), ("geom_tmp", _vp), ("image_buffer", _vp), ("point_list", _vp),
-        ("binning_tmp", _vp), ("sorted_rec", _vp), ("group_ids", _vp), ("num_groups", C.c_int32),
+        ("binning_tmp", _vp), ("sorted_rec", _vp), ("quad_list", _vp), ("group_ids", _vp), ("num_groups", C.c_int32),
     ]
 
 
@@ -39,7 +39,7 @@ class OgsRasterBwdArgs(C.Structure):
         ("scales", _vp), ("rotations", _vp), ("cov3D_precomp", _vp),
         ("viewmatrix", _vp), ("projmatrix", _vp), ("campos", _vp),
         ("radii", _vp), ("out_alpha", _vp), ("dL_dcolor", _vp), ("dL_ddepth", _vp), ("dL_dalpha", _vp),
-        ("geom_buffer", _vp), ("image_buffer", _vp), ("point_list", _vp), ("sorted_rec", _vp), ("bwd_tmp", _vp),
+        ("geom_buffer", _vp), ("image_buffer", _vp), ("point_list", _vp), ("sorted_rec", _vp), ("quad_list", _vp), ("bwd_tmp", _vp),
         ("dL_dmeans2D", _vp), ("dL_dcolors", _vp), ("dL_dopacity", _vp), ("dL_dmeans3D", _vp),
         ("dL_dcov3D", _vp), ("dL_dsh", _vp), ("dL_dscales", _vp), ("dL_drotations", _vp), ("num_groups", C.c_int32), ("dL_dsh_rgb", _vp),
     ]
@@ -61,6 +61,7 @@ SIGNATURES = {
     "ogs_raster_binning_tmp_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     "ogs_raster_backward_tmp_bytes": (C.c_size_t, [C.c_int32]),
     "ogs_raster_sorted_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
+    "ogs_raster_quad_list_bytes": (C.c_size_t, [C.c_int64]),
     "ogs_raster_forward_geometry": (C.c_int, [C.POINTER(OgsRasterFwdArgs), _vp, C.POINTER(C.c_int64)]),
     "ogs_raster_forward_render": (C.c_int, [C.POINTER(OgsRasterFwdArgs), C.c_int64, _vp]),
     "ogs_raster_read_num_rendered_async": (C.c_int, [C.POINTER(OgsRasterFwdArgs), _vp, _vp]),

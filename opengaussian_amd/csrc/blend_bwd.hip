@@ -37,8 +37,8 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 // gaussian_renderer/__init__.py:362 "not used"): the depth recursion and its dL/dalpha term are compiled out.
 template <int C, int GC, bool DEPTH>
 __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
-    const uint2* __restrict__ ranges, const float* __restrict__ stream, int W, int H, int gx, int tiles,
-    const float* __restrict__ bg, const float* __restrict__ out_alpha, const uint32_t* __restrict__ n_contrib,
+    const uint2* __restrict__ ranges, const float* __restrict__ stream, const uint32_t* __restrict__ quad_list, int W,
+    int H, int gx, int tiles, const float* __restrict__ bg, const float* __restrict__ out_alpha, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha_map,
     float* __restrict__ grad_rec) {
     constexpr int RS = stream_vec4(C) * 4;
@@ -63,7 +63,10 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     if (hi == 0) return;                                 // wave-uniform; no barriers in this kernel
     // this wave's quadrant stream (blend_fwd.hip::pack_sorted_kernel); n_contrib indexes into it
     const int n_tile = (int)(range.y - range.x);
-    const float* __restrict__ base = stream + ((size_t)range.x * 4 + (size_t)wave * n_tile) * RS;
+    const float* __restrict__ tb = stream + (size_t)range.x * RS;                                    // tile's records
+    const uint32_t* __restrict__ qi = quad_list + ((size_t)range.x * 4 + (size_t)wave * n_tile);     // quadrant's indices
+    const uint32_t lim = n_tile > 0 ? (uint32_t)n_tile - 1u : 0u;
+    auto rec_at = [&](uint32_t i) { return tb + (size_t)(min(i, lim) * (uint32_t)RS); };
 
     const float T_final = inside ? 1.0f - out_alpha[pix] : 0.f;
     float T = T_final;
@@ -174,18 +177,20 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
             }
         }
     };
+    // back-to-front over the quadrant's index stream (see blend_fwd.hip): two records in flight, their indices
+    // fetched one iteration ahead; reads below index 0 land in the previous region / the front pad and are clamped
     StreamRec<C> recA, recB;
-    recA.load(base + (size_t)(hi - 1) * RS);
-    // `p` = lowest address the iteration loads from (entry idx-2), so both records are reached with non-negative
-    // immediate s_load offsets (see blend_fwd.hip); it may run into the front pad / the previous tile: those
-    // records are loaded but never consumed
-    const float* __restrict__ p = base + ((ptrdiff_t)hi - 3) * RS;      // wave-uniform -> scalar loads
+    const uint32_t* __restrict__ q = qi + (hi - 1);
+    uint32_t i1 = q[-1], i2 = q[-2];
+    recA.load(rec_at(q[0]));
     for (int idx = hi - 1; idx >= 0; idx -= 2) {
-        recB.load(p + RS);
+        recB.load(rec_at(i1));
+        const uint32_t n3 = q[-3], n4 = q[-4];
         consume(recA, idx);
-        recA.load(p);
+        recA.load(rec_at(i2));
         if (idx > 0) consume(recB, idx - 1);
-        p -= 2 * RS;
+        i1 = n3; i2 = n4;
+        q -= 2;
     }
 }
 
@@ -203,10 +208,11 @@ int launch_c(const OgsRasterBwdArgs& a, const ImageState& is, float* grad_rec, h
     static constexpr const char* const kNames[4] = {"blend_backward_kernel<3>", "blend_backward_kernel<6>",
                                                     "blend_backward_kernel<9>", "blend_backward_kernel<12>"};
     const float* stream = (const float*)stream_base<C>(const_cast<void*>(a.sorted_rec));
+    const uint32_t* quads = quad_base(const_cast<void*>(a.quad_list));
     const unsigned vtiles = (unsigned)(gx * gy) * (unsigned)num_groups_of(a.num_groups);
 #define OGS_BWD_LAUNCH(GCV, DEPTHV)                                                                                  \
     OGS_LAUNCH_NAMED(chan_name<C>(kNames), (blend_backward_kernel<C, GCV, DEPTHV>), dim3(vtiles), dim3(kBlock), 0, s,   \
-                     (const uint2*)is.ranges, stream, a.W, a.H, gx, gx * gy, a.bg, a.out_alpha,                         \
+                     (const uint2*)is.ranges, stream, quads, a.W, a.H, gx, gx * gy, a.bg, a.out_alpha,                  \
                      (const uint32_t*)is.n_contrib, a.dL_dcolor, a.dL_ddepth, a.dL_dalpha, grad_rec)
     const bool depth = a.dL_ddepth != nullptr;
     if (a.geom_channels <= 0 || a.geom_channels >= C) {

@@ -58,6 +58,7 @@ __global__ __launch_bounds__(kBlock) void pack_sorted_kernel(const uint2* __rest
                                                              const uint32_t* __restrict__ point_list, int gx,
                                                              int tiles, const float4* __restrict__ rec,
                                                              float4* __restrict__ stream,
+                                                             uint32_t* __restrict__ quad_list,
                                                              uint32_t* __restrict__ qcount) {
     constexpr int NV = rec_vec4(C);
     constexpr int SV = stream_vec4(C);
@@ -122,18 +123,19 @@ __global__ __launch_bounds__(kBlock) void pack_sorted_kernel(const uint2* __rest
         }
         const uint64_t pos = before + inc - mine;          // exclusive position inside this chunk, per quadrant
         if (mask) {
-            const float4 r0 = make_float4(a.x, a.y, -0.5f * b.x, -b.y);
-            const float4 r1 = make_float4(-0.5f * b.z, h, b.w, __uint_as_float(gid_of_thread));
+            // ONE copy of the record, at the entry's own position in the tile list (consecutive threads ->
+            // consecutive 16*SV-byte records) ...
+            float4* dst = stream + ((size_t)range.x + (size_t)i) * SV;
+            dst[0] = make_float4(a.x, a.y, -0.5f * b.x, -b.y);
+            dst[1] = make_float4(-0.5f * b.z, h, b.w, __uint_as_float(gid_of_thread));
+#pragma unroll
+            for (int v = 0; v < SV - 2; ++v) dst[2 + v] = make_float4(f[4 * v], f[4 * v + 1], f[4 * v + 2], f[4 * v + 3]);
+            // ... and its tile-local index appended to the index stream of every quadrant it can reach
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (mask & (1u << q)) {
                     const uint32_t p = running[q] + ((uint32_t)(pos >> (16 * q)) & 0xFFFFu);
-                    float4* dst = stream + ((size_t)range.x * 4 + (size_t)q * n + p) * SV;
-                    dst[0] = r0;
-                    dst[1] = r1;
-#pragma unroll
-                    for (int v = 0; v < SV - 2; ++v)
-                        dst[2 + v] = make_float4(f[4 * v], f[4 * v + 1], f[4 * v + 2], f[4 * v + 3]);
+                    quad_list[(size_t)range.x * 4 + (size_t)q * n + p] = (uint32_t)i;
                 }
             }
         }
@@ -149,8 +151,8 @@ __global__ __launch_bounds__(kBlock) void pack_sorted_kernel(const uint2* __rest
 
 template <int C>
 __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ qcount, const float* __restrict__ stream, int W,
-    int H, int gx, int tiles, const float* __restrict__ bg, float* __restrict__ out_color,
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ qcount, const float* __restrict__ stream,
+    const uint32_t* __restrict__ quad_list, int W, int H, int gx, int tiles, const float* __restrict__ bg, float* __restrict__ out_color,
     float* __restrict__ out_depth, float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib) {
     constexpr int RS = stream_vec4(C) * 4;      // floats per stream record
     const int tile = blockIdx.x;                // virtual tile (grouped pass): image * tiles + tile in the image
@@ -165,7 +167,11 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
     const uint2 range = ranges[tile];
     const int n_tile = (int)(range.y - range.x);
     const int n = (int)qcount[tile * 4 + wave];                        // this quadrant's kept entries
-    const float* __restrict__ base = stream + ((size_t)range.x * 4 + (size_t)wave * n_tile) * RS;
+    const float* __restrict__ tb = stream + (size_t)range.x * RS;                                    // tile's records
+    const uint32_t* __restrict__ qi = quad_list + ((size_t)range.x * 4 + (size_t)wave * n_tile);     // quadrant's indices
+    const uint32_t lim = n_tile > 0 ? (uint32_t)n_tile - 1u : 0u;
+    // index -> record address; whatever the two-ahead prefetch reads past the end of the region is clamped
+    auto rec_at = [&](uint32_t i) { return tb + (size_t)(min(i, lim) * (uint32_t)RS); };
 
     // The loop is written to be SCALAR-ALU frugal (rocprof: the first version issued more SALU than VALU
     // instructions -- one scalar unit per CU -- because every nested divergent `if` costs exec-mask ops):
@@ -211,20 +217,20 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
             if (__ballot(stop) != 0ull) all_done = __ballot(fxe < kFarTest) == 0ull;   // whole wave finished?
         }
     };
-    // software pipeline over the wave-uniform stream: the stream buffer is padded on both ends and quadrant
-    // regions are contiguous, so prefetching up to two records past the end needs no bounds test
-    StreamRec<C> recA, recB;
-    recA.load(base);
-    // `p` always points at the LOWEST address the iteration loads from, so that both records are reached with
-    // non-negative immediate offsets of s_load (gfx9-family SMEM offsets are unsigned; a pointer that runs ahead
-    // costs an s_add_u32/s_addc_u32 pair per load)
-    const float* __restrict__ p = base + RS;
-    for (int j = 0; j < n && !all_done; j += 2) {
-        recB.load(p);
-        consume(recA, j);
-        recA.load(p + RS);
-        if (j + 1 < n) consume(recB, j + 1);
-        p += 2 * RS;
+    // software pipeline over the wave-uniform index stream: records of entries j+1 and j+2 are in flight while
+    // entry j is blended, their indices were fetched one iteration earlier (all scalar loads)
+    if (n > 0) {
+        StreamRec<C> recA, recB;
+        uint32_t i1 = qi[1], i2 = qi[2];
+        recA.load(rec_at(qi[0]));
+        for (int j = 0; j < n && !all_done; j += 2) {
+            recB.load(rec_at(i1));
+            const uint32_t n3 = qi[j + 3], n4 = qi[j + 4];
+            consume(recA, j);
+            recA.load(rec_at(i2));
+            if (j + 1 < n) consume(recB, j + 1);
+            i1 = n3; i2 = n4;
+        }
     }
 
     if (inside) {
@@ -244,10 +250,9 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
 template <int C>
 __global__ __launch_bounds__(kBlock) void export_n_contrib_kernel(const uint2* __restrict__ ranges,
                                                                   const uint32_t* __restrict__ point_list,
-                                                                  const float* __restrict__ stream, int W, int H, int gx,
-                                                                  int tiles, const uint32_t* __restrict__ n_contrib,
+                                                                  const uint32_t* __restrict__ quad_list, int W, int H,
+                                                                  int gx, int tiles, const uint32_t* __restrict__ n_contrib,
                                                                   uint32_t* __restrict__ out) {
-    constexpr int RS = stream_vec4(C) * 4;
     const int tile = blockIdx.x;
     const int img = tile / tiles, timg = tile - img * tiles;
     const int tx = timg % gx, ty = timg / gx;
@@ -260,13 +265,9 @@ __global__ __launch_bounds__(kBlock) void export_n_contrib_kernel(const uint2* _
     n_contrib += (size_t)img * W * H;
     out += (size_t)img * W * H;
     const uint32_t last = n_contrib[(size_t)py * W + px];
+    // n_contrib counts inside the quadrant's index stream; the stream entry IS the position in the tile list
     uint32_t res = 0;
-    if (last > 0) {
-        const float* r = stream + ((size_t)range.x * 4 + (size_t)wave * n_tile + (last - 1)) * RS;
-        const uint32_t gid = __float_as_uint(r[7]);
-        for (int i = 0; i < n_tile; ++i)
-            if (point_list[range.x + i] == gid) { res = (uint32_t)i + 1u; break; }
-    }
+    if (last > 0) res = quad_list[(size_t)range.x * 4 + (size_t)wave * n_tile + (last - 1)] + 1u;
     out[(size_t)py * W + px] = res;
 }
 
@@ -280,7 +281,7 @@ int launch_c(const OgsRasterFwdArgs& a, const GeomState& gs, const ImageState& i
                                                        "pack_sorted_kernel<9>", "pack_sorted_kernel<12>"};
         OGS_LAUNCH_NAMED(chan_name<C>(kPack), pack_sorted_kernel<C>, dim3(vtiles), dim3(kBlock), 0, s,
                          (const uint2*)is.ranges, (const uint32_t*)a.point_list, gx, tiles, (const float4*)gs.rec,
-                         stream_base<C>(a.sorted_rec), is.qcount);
+                         stream_base<C>(a.sorted_rec), quad_base(a.quad_list), is.qcount);
         OGS_LAUNCH_CHECK(a.debug, s);
     } else {
         OGS_HIP_CHECK(hipMemsetAsync(is.qcount, 0, (size_t)vtiles * 4 * sizeof(uint32_t), s));
@@ -288,8 +289,9 @@ int launch_c(const OgsRasterFwdArgs& a, const GeomState& gs, const ImageState& i
     static constexpr const char* const kNames[4] = {"blend_forward_kernel<3>", "blend_forward_kernel<6>",
                                                     "blend_forward_kernel<9>", "blend_forward_kernel<12>"};
     OGS_LAUNCH_NAMED(chan_name<C>(kNames), blend_forward_kernel<C>, dim3(vtiles), dim3(kBlock), 0, s,
-                     (const uint2*)is.ranges, (const uint32_t*)is.qcount, (const float*)stream_base<C>(a.sorted_rec), a.W,
-                     a.H, gx, tiles, a.bg, a.out_color, a.out_depth, a.out_alpha, is.n_contrib);
+                     (const uint2*)is.ranges, (const uint32_t*)is.qcount, (const float*)stream_base<C>(a.sorted_rec),
+                     (const uint32_t*)quad_base(a.quad_list), a.W, a.H, gx, tiles, a.bg, a.out_color, a.out_depth,
+                     a.out_alpha, is.n_contrib);
     OGS_LAUNCH_CHECK(a.debug, s);
     return OGS_OK;
 }
@@ -298,7 +300,7 @@ template <int C>
 int export_c(const OgsRasterFwdArgs& a, const ImageState& is, uint32_t* out, hipStream_t s) {
     const int gx = (a.W + kTile - 1) / kTile, gy = (a.H + kTile - 1) / kTile;
     OGS_LAUNCH(export_n_contrib_kernel<C>, dim3((unsigned)(gx * gy) * (unsigned)num_groups_of(a.num_groups)), dim3(kBlock), 0,
-               s, (const uint2*)is.ranges, (const uint32_t*)a.point_list, (const float*)stream_base<C>(a.sorted_rec), a.W,
+               s, (const uint2*)is.ranges, (const uint32_t*)a.point_list, (const uint32_t*)quad_base(a.quad_list), a.W,
                a.H, gx, gx * gy, (const uint32_t*)is.n_contrib, out);
     OGS_LAUNCH_CHECK(0, s);
     return OGS_OK;

@@ -143,8 +143,12 @@ size_t ogs_raster_image_bytes(int32_t W, int32_t H) { return ImageState::bytes(W
 size_t ogs_raster_image_bytes_grouped(int32_t W, int32_t H, int32_t G) { return ImageState::bytes(W, H, num_groups_of(G)); }
 size_t ogs_raster_binning_tmp_bytes(int64_t D, int32_t, int32_t) { return BinTmp::bytes(D > 0 ? D : 1); }
 size_t ogs_raster_sorted_bytes(int64_t D, int32_t C) {
-    // every tile owns four quadrant regions of capacity n_tile each (only the kept ~1.1 x D records are touched)
-    return align_up((size_t)(4 * (D > 0 ? D : 1) + kStreamPad) * stream_vec4(C) * sizeof(float4));
+    return align_up((size_t)(D > 0 ? D : 1) * stream_vec4(C) * sizeof(float4));
+}
+size_t ogs_raster_quad_list_bytes(int64_t D) {
+    // four quadrant regions of capacity n_tile per tile (only the kept ~1.1 x D indices are written) + slack for the
+    // blend loops' two-ahead index prefetch on either side
+    return align_up((size_t)(4 * (D > 0 ? D : 1) + 2 * kQuadPad) * sizeof(uint32_t));
 }
 size_t ogs_raster_backward_tmp_bytes(int32_t P) { return align_up((size_t)(P > 0 ? P : 1) * 16 * sizeof(float)); }
 
@@ -223,7 +227,7 @@ static int render_impl(const OgsRasterFwdArgs* a, int64_t D, bool deferred, hipS
     } else {
         OGS_HIP_CHECK(hipMemsetAsync(is.ranges, 0, (size_t)tiles * sizeof(uint2), s));
     }
-    if (D > 0 && !a->sorted_rec) { set_error("sorted_rec == NULL with num_rendered=%lld", (long long)D); return OGS_ERR_INVALID_ARG; }
+    if (!a->sorted_rec || !a->quad_list) { set_error("sorted_rec / quad_list == NULL"); return OGS_ERR_INVALID_ARG; }
     return launch_blend_forward(*a, gs, is, D, s);
 }
 
@@ -251,7 +255,7 @@ int ogs_raster_backward(const OgsRasterBwdArgs* a, void* stream_) {
     const ImageState is = ImageState::carve(const_cast<void*>(a->image_buffer), a->W, a->H, num_groups_of(a->num_groups));
     float* grad_rec = static_cast<float*>(a->bwd_tmp);
     OGS_HIP_CHECK(hipMemsetAsync(grad_rec, 0, (size_t)a->P * grad_stride(a->C) * sizeof(float), s));
-    if (a->num_rendered > 0 && !a->sorted_rec) { set_error("backward: sorted_rec == NULL"); return OGS_ERR_INVALID_ARG; }
+    if (a->num_rendered > 0 && (!a->sorted_rec || !a->quad_list)) { set_error("backward: sorted_rec / quad_list == NULL"); return OGS_ERR_INVALID_ARG; }
     int rc = launch_blend_backward(*a, is, grad_rec, s);
     if (rc != OGS_OK) return rc;
     return launch_preprocess_backward(*a, gs, grad_rec, s);

@@ -84,16 +84,20 @@ struct Carver {
 //   f4[2..] = C blended feature channels, zero padded to a multiple of 4
 __host__ __device__ constexpr int rec_vec4(int C) { return 2 + (C + 3) / 4; }   // float4 per record
 
-// Per sorted-list-entry stream record read by the blend kernels through the scalar path (blend_fwd.hip):
+// Per sorted-list-entry record read by the blend kernels through the scalar path (blend_fwd.hip):
 // 8 geometry floats (the last is the Gaussian id) + C features + depth, padded to float4.
 __host__ __device__ constexpr int stream_vec4(int C) { return (8 + C + 1 + 3) / 4; }
 
-// The stream buffer carries two unused records in front of entry 0 (one is skipped by stream_base... the
-// backward walk prefetches up to two entries ahead) and two behind entry D-1, so the blend loops can
-// prefetch "the next two records" without a bounds test in either walking direction.
-constexpr int kStreamPad = 4;
+// Blend-side layout (blend_fwd.hip): `sorted_rec` holds ONE packed record per entry of the sorted (Gaussian, tile)
+// list, at the entry's position (written only when some quadrant of the tile can be reached); `quad_list` holds,
+// per (tile, 8x8 quadrant), the tile-local indices of the entries that quadrant keeps, depth order preserved:
+// region of quadrant q of a tile with list [start, start + n) = quad_list[4*start + q*n ... + n).  The blend
+// loops prefetch two indices past either end of a region (kQuadPad u32 of slack in front and behind) and clamp
+// whatever they read to [0, n-1] before touching a record.
+constexpr int kQuadPad = 8;
 template <int C>
-inline float4* stream_base(void* buf) { return static_cast<float4*>(buf) + 2 * stream_vec4(C); }
+inline float4* stream_base(void* buf) { return static_cast<float4*>(buf); }
+inline uint32_t* quad_base(void* buf) { return static_cast<uint32_t*>(buf) + kQuadPad; }
 // A pixel that is finished (or outside the image) is parked at this x coordinate: its quadratic form
 // becomes hugely negative, so the single candidate compare of the blend loops rejects it.
 constexpr float kFar = 3.0e18f;

@@ -163,8 +163,9 @@ class _RasterizeGaussians(torch.autograd.Function):
             pl = torch.empty(max(count, 1), dtype=torch.int32, device=dev)
             bt = u8(lib.ogs_raster_binning_tmp_bytes(count, W, H))
             sr = u8(lib.ogs_raster_sorted_bytes(count, Cn))
-            a.point_list, a.binning_tmp, a.sorted_rec = ptr(pl), ptr(bt), ptr(sr)
-            return pl, bt, sr
+            ql = u8(lib.ogs_raster_quad_list_bytes(count))
+            a.point_list, a.binning_tmp, a.sorted_rec, a.quad_list = ptr(pl), ptr(bt), ptr(sr), ptr(ql)
+            return pl, bt, sr, ql
 
         key = (P, W, H, G)
         last = _LAST_NUM_RENDERED.get(key)
@@ -173,7 +174,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             n = C.c_int64(0)
             check(lib.ogs_raster_forward_geometry(C.byref(a), stream, C.byref(n)), "ogs_raster_forward_geometry")
             D = int(n.value)
-            point_list, bin_tmp, sorted_rec = alloc_render(D)
+            point_list, bin_tmp, sorted_rec, quad_list = alloc_render(D)
             check(lib.ogs_raster_forward_render(C.byref(a), D, stream), "ogs_raster_forward_render")
         else:
             # steady state: no GPU idle gap.  The render phase is enqueued for a capacity derived from the last
@@ -185,12 +186,12 @@ class _RasterizeGaussians(torch.autograd.Function):
                   "ogs_raster_read_num_rendered_async")
             ev.record()
             cap = int(last * 1.25) + 4096
-            point_list, bin_tmp, sorted_rec = alloc_render(cap)
+            point_list, bin_tmp, sorted_rec, quad_list = alloc_render(cap)
             check(lib.ogs_raster_forward_render_deferred(C.byref(a), cap, stream), "ogs_raster_forward_render_deferred")
             ev.synchronize()
             D = int(pinned.item()) & 0xFFFFFFFF
             if D > cap:
-                point_list, bin_tmp, sorted_rec = alloc_render(D)
+                point_list, bin_tmp, sorted_rec, quad_list = alloc_render(D)
                 check(lib.ogs_raster_forward_render(C.byref(a), D, stream), "ogs_raster_forward_render")
         if len(_LAST_NUM_RENDERED) > 256:      # subset renders come in many sizes: keep the hint table small
             _LAST_NUM_RENDERED.clear()
@@ -198,7 +199,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         ctx.num_rendered = D
         ctx.save_for_backward(m3, shs, cols, opac, scl, rot, cov, bg, view, proj, campos, radii, alpha, geom, image,
-                              point_list, sorted_rec)
+                              point_list, sorted_rec, quad_list)
         ctx.mark_non_differentiable(radii)
         return color, radii, depth, alpha
 
@@ -209,7 +210,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         if P == 0:
             return (None,) * 13
         (m3, shs, cols, opac, scl, rot, cov, bg, view, proj, campos, radii, alpha, geom, image,
-         point_list, sorted_rec) = ctx.saved_tensors
+         point_list, sorted_rec, quad_list) = ctx.saved_tensors
         dev = m3.device
         lib = _lib.lib()
         H, W = int(rs.image_height), int(rs.image_width)
@@ -244,7 +245,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         b.num_rendered = int(ctx.num_rendered)
         b.geom_channels = int(ctx.geom_channels)
         b.num_groups = int(ctx.num_groups)
-        b.sorted_rec = ptr(sorted_rec)
+        b.sorted_rec, b.quad_list = ptr(sorted_rec), ptr(quad_list)
         b.bg, b.means3D, b.colors_precomp, b.shs, b.opacities = ptr(bg), ptr(m3), ptr(cols), ptr(shs), ptr(opac)
         b.scales, b.rotations, b.cov3D_precomp = ptr(scl), ptr(rot), ptr(cov)
         b.viewmatrix, b.projmatrix, b.campos = ptr(view), ptr(proj), ptr(campos)

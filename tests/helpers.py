@@ -71,7 +71,7 @@ def hip_export_binning(color_tensor):
     fn = color_tensor.grad_fn
     ctx = fn
     (m3, shs, cols, opac, scl, rot, cov, bg, view, proj, campos, radii, alpha, geom, image,
-     point_list, sorted_rec) = ctx.saved_tensors
+     point_list, sorted_rec, quad_list) = ctx.saved_tensors
     rs = ctx.raster_settings
     D = ctx.num_rendered
     W, H = int(rs.image_width), int(rs.image_height)
@@ -83,7 +83,7 @@ def hip_export_binning(color_tensor):
     a = OgsRasterFwdArgs()
     a.P, a.W, a.H, a.C = ctx.P, W, H, ctx.Cn
     a.geom_buffer, a.image_buffer, a.point_list = ptr(geom), ptr(image), ptr(point_list)
-    a.sorted_rec = ptr(sorted_rec)
+    a.sorted_rec, a.quad_list = ptr(sorted_rec), ptr(quad_list)
     _lib.check(_lib.lib().ogs_raster_export_binning(C.byref(a), D, ptr(keys), ptr(ranges), ptr(ncontrib),
                                                     torch.cuda.current_stream().cuda_stream), "export_binning")
     torch.cuda.synchronize()
