@@ -75,22 +75,13 @@ __global__ __launch_bounds__(kBlock) void pack_sorted_kernel(const uint2* __rest
         const int i = base + tid;
         uint32_t mask = 0;
         float4 a = make_float4(0, 0, 0, 0), b = a;
-        float f[(SV - 2) * 4];
-#pragma unroll
-        for (int k = 0; k < (SV - 2) * 4; ++k) f[k] = 0.f;
         float h = 0.f;
         uint32_t gid_of_thread = 0;
         if (i < n) {
             const uint32_t gid = point_list[range.x + i];
             gid_of_thread = gid;
             const float4* src = rec + (size_t)gid * NV;
-            a = src[0]; b = src[1];
-#pragma unroll
-            for (int v = 0; v < NV - 2; ++v) {
-                const float4 t = src[2 + v];
-                f[4 * v] = t.x; f[4 * v + 1] = t.y; f[4 * v + 2] = t.z; f[4 * v + 3] = t.w;
-            }
-            f[C] = a.z;                          // view depth rides next to the features (slot C)
+            a = src[0]; b = src[1];              // geometry only: the features are fetched if the entry survives
             // candidate window thr <= power <= 0, thr = ln(1/(255*opacity)) - margin; stored as h = -thr/2 so the
             // blend loops test it with ONE compare |power + h| <= h (opacity <= 0: NaN/-inf, never a candidate)
             h = 0.5f * (__logf(255.0f * b.w) + kThrMargin);
@@ -128,6 +119,18 @@ __global__ __launch_bounds__(kBlock) void pack_sorted_kernel(const uint2* __rest
             float4* dst = stream + ((size_t)range.x + (size_t)i) * SV;
             dst[0] = make_float4(a.x, a.y, -0.5f * b.x, -b.y);
             dst[1] = make_float4(-0.5f * b.z, h, b.w, __uint_as_float(gid_of_thread));
+            // features (gathered only now: 52 % of the bench scene's entries reach no quadrant), then the view
+            // depth in slot C, zero padding behind it
+            const float4* src = rec + (size_t)gid_of_thread * NV;
+            float f[(SV - 2) * 4];
+#pragma unroll
+            for (int k = 0; k < (SV - 2) * 4; ++k) f[k] = 0.f;
+#pragma unroll
+            for (int v = 0; v < NV - 2; ++v) {
+                const float4 t = src[2 + v];
+                f[4 * v] = t.x; f[4 * v + 1] = t.y; f[4 * v + 2] = t.z; f[4 * v + 3] = t.w;
+            }
+            f[C] = a.z;
 #pragma unroll
             for (int v = 0; v < SV - 2; ++v) dst[2 + v] = make_float4(f[4 * v], f[4 * v + 1], f[4 * v + 2], f[4 * v + 3]);
             // ... and its tile-local index appended to the index stream of every quadrant it can reach
