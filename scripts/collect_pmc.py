@@ -23,7 +23,7 @@ def per_kernel(dirname, counter):
             if not m or "ogs::" not in r["Kernel_Name"]:
                 continue
             name = m.group(1)
-            name = re.sub(r"<(\d+), \d+>", r"<\1>", name)          # blend_backward_kernel<9, 3> -> <9> (bench.py's name)
+            name = re.sub(r"<(\d+),[^>]*>", r"<\1>", name)
             a = acc[name]
             a[0] += float(r["Counter_Value"])
             a[1] += 1
