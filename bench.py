@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="S1M-1080p", choices=["S1M-1080p", "C2-100k-800"])
+    ap.add_argument("--workload", default="S1M-1080p", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tile-stride", type=int, default=8, help="CPU baseline renders this many full tile rows")
     ap.add_argument("--no-kmeans", action="store_true")
@@ -65,6 +65,7 @@ def parse():
 WORKLOADS = {
     "S1M-1080p": dict(P=1_000_000, W=1920, H=1080, f=1000.0),
     "C2-100k-800": dict(P=100_000, W=800, H=800, f=700.0),
+    "C4-2M-648": dict(P=2_000_000, W=648, H=484, f=500.0),      # ScanNet-class: many Gaussians, small image
 }
 
 

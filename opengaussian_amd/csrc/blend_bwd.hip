@@ -1,7 +1,8 @@
 // Backward alpha blend for gfx950 -- scalar-path design (see blend_fwd.hip).
 //
-// One workgroup per 16x16 tile, each wave64 owns an 8x8 quadrant and walks the packed per-tile stream
-// BACK-TO-FRONT from its own last contributor with wave-uniform scalar loads: no LDS, no barriers.
+// One workgroup per 16x16 tile, each wave64 owns an 8x8 quadrant and walks ITS index stream (blend_fwd.hip)
+// BACK-TO-FRONT from its own last contributor, indices and records fetched with wave-uniform scalar loads:
+// no LDS, no barriers.
 // Per (pixel, Gaussian) the C+7 partial gradients are NOT sent to memory one float atomic each (the
 // reference's ~10 atomics per pair): the 64 lanes hold a 16-slot vector each, folded with a transposed
 // butterfly

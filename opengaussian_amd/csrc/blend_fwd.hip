@@ -1,23 +1,28 @@
 // Forward front-to-back alpha blend for gfx950 -- scalar-path design over
-// per-quadrant compacted streams.
+// per-quadrant compacted index streams.
 //
 // History (profiles/): (v1) the classic "stage 256 Gaussians in LDS, every pixel thread
-// re-reads them" loop; (v2) the staged data is wave-uniform, so it moved to the SCALAR path: a packed
-// per-tile record stream read with s_load into SGPRs, no LDS, no barriers; (v3) SQ counters showed the loop
-// SALU-bound -> branch-free body; (v4, this file) measured on the bench scene only 48 % of the reference's
-// (Gaussian, tile) list entries can reach alpha >= 1/255 on ANY pixel of their tile and only 28 % of the
-// (entry, 8x8 quadrant) pairs -- the reference's tile rect is the square around ceil(3 sigma_max).
+// re-reads them" loop; (v2) the staged data is wave-uniform, so it moved to the SCALAR path: packed records
+// read with s_load into SGPRs, no LDS, no barriers; (v3) SQ counters showed the loop SALU-bound -> branch-free
+// body; (v4) measured on the bench scene only 48 % of the reference's (Gaussian, tile) list entries can reach
+// alpha >= 1/255 on ANY pixel of their tile and only 28 % of the (entry, 8x8 quadrant) pairs -- the reference's
+// tile rect is the square around ceil(3 sigma_max) -> per-quadrant streams; (v9, this file) the streams hold
+// 4-byte indices and every record is stored once per tile entry.
 //
-//   1. pack_sorted_kernel: one workgroup per tile walks the tile's sorted list, gathers each Gaussian's
-//      record (the only random reads of the pass), runs an EXACT conservative test per 8x8 quadrant
-//      (maximum of the Gaussian's quadratic form over the quadrant's pixel box vs ln(1/(255*opacity)) - margin)
-//      and appends the record to the stream of every quadrant it can reach.  Depth order inside a quadrant
-//      stream is preserved with a block-wide prefix sum over four 16-bit counters packed in one u64.  The
-//      reference-visible binning state (sorted keys, point list, tile ranges) is untouched and stays bit-exact;
-//      dropped entries are exactly those every lane of the quadrant would have skipped.
-//   2. blend_forward_kernel: one workgroup per tile, each wave64 owns one quadrant and walks ITS stream with
-//      wave-uniform scalar loads (s_load_dwordx8/x4 -> SGPR operands of the per-pixel VALU math).  ~3.6x fewer
-//      loop trips than walking the tile list, nearly all of them doing useful blending.
+//   1. pack_sorted_kernel: one workgroup per tile walks the tile's sorted list, gathers the geometry half of
+//      each Gaussian's record (the only random reads of the pass), runs an EXACT conservative test per 8x8
+//      quadrant (maximum of the Gaussian's quadratic form over the quadrant's pixel box vs
+//      ln(1/(255*opacity)) - margin) and appends the entry's tile-local INDEX to the stream of every quadrant it
+//      can reach; a surviving entry gathers its feature half and writes one packed record at its own list
+//      position.  Depth order inside a quadrant stream is preserved with a block-wide prefix sum over four
+//      16-bit counters packed in one u64.  The reference-visible binning state (sorted keys, point list, tile
+//      ranges) is untouched and stays bit-exact; dropped entries are exactly those every lane of the quadrant
+//      would have skipped.
+//   2. blend_forward_kernel: one workgroup per tile, each wave64 owns one quadrant and walks ITS index stream;
+//      indices and records are fetched with wave-uniform scalar loads (s_load_dwordx2, then s_load_dwordx16 + x2
+//      -> SGPR operands of the per-pixel VALU math), records two entries ahead of their use.  ~3.6x fewer loop
+//      trips than walking the tile list, nearly all of them doing useful blending; the four waves of a tile
+//      share the records in the scalar cache.
 // No MFMA: the loop is a per-pixel recurrence, not a contraction.
 #include "ogs_common.h"
 
@@ -48,7 +53,7 @@ __device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d) {
     return ((uint64_t)hi << 32) | lo;
 }
 
-// stream record (per kept (entry, quadrant) pair):
+// blend record (one per tile-list entry that reaches some quadrant, at the entry's list position):
 //   [0] x  [1] y  [2] -0.5*A  [3] -B  [4] -0.5*C  [5] h=-thr/2  [6] opacity  [7] Gaussian id (bit pattern)
 //   [8..8+C) features  [8+C] view depth, rest zero padding to a multiple of 4 floats.
 // The depth sits right behind the features so that the (feature, feature) / (feature, depth) operand pairs of
