@@ -386,3 +386,57 @@ def test_grouped_pass_equals_subset_renders(gpu_device, use_sh, G):
         scale = float(want.abs().max()) + 1e-20
         assert float((got - want).abs().max()) / scale < 2e-4, n
     assert float((m2.grad - m2b.grad).abs().max()) / (float(m2b.grad.abs().max()) + 1e-20) < 2e-4
+
+
+@pytest.mark.parametrize("sh_degree,sh_coeffs,scale_modifier,use_cov", [(0, 16, 1.0, False), (1, 16, 0.7, False),
+                                                                         (2, 9, 1.3, False), (0, 1, 1.0, True),
+                                                                         (3, 16, 0.5, False)])
+def test_sh_degrees_coefficient_counts_and_scale_modifier(gpu_device, sh_degree, sh_coeffs, scale_modifier, use_cov):
+    """active SH degree below the stored one (the reference raises it every 1000 iterations, train.py:267-268),
+    SH tensors with fewer than 16 coefficients, and scale_modifier != 1 (render(..., scaling_modifier)): forward
+    parity with the oracle, and gradients against float64 autograd.  The reference's scale gradient omits the
+    modifier factor (Appendix A.5(v)), so dL/dscales is compared for modifier 1 only."""
+    from oracle import raster_oracle as ro
+    from opengaussian_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    import math
+    P, W, H, f = 1800, 144, 88, 110.0
+    sc, cam = helpers.tiny_scene(P, W, H, f, seed=50 + sh_degree)
+    inp = helpers.oracle_inputs(sc, cam, use_sh=True, use_cov=False)
+    inp["shs"] = np.ascontiguousarray(inp["shs"][:, :sh_coeffs])
+    if use_cov:
+        inp["cov3D_precomp"] = ro.cov3d_from_scale_rot(inp.pop("scales"), inp.pop("rotations"), scale_modifier)
+    bg = (0.05, 0.1, 0.15)
+    ref = ro.render_forward(W=W, H=H, tanfovx=W / (2 * f), tanfovy=H / (2 * f), bg=np.array(bg, np.float32),
+                            sh_degree=sh_degree, scale_modifier=scale_modifier, **inp)
+    dev = gpu_device
+    t = lambda k: (None if inp.get(k) is None else torch.tensor(np.asarray(inp[k]), dtype=torch.float32, device=dev, requires_grad=True))
+    leaves = {k: t(k) for k in ("means3D", "opacities", "scales", "rotations", "cov3D_precomp", "shs")}
+    m2 = torch.zeros(P, 3, device=dev, requires_grad=True)
+    st = GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
+        bg=torch.tensor(bg, device=dev), scale_modifier=scale_modifier, viewmatrix=cam.world_view_transform.to(dev),
+        projmatrix=cam.full_proj_transform.to(dev), sh_degree=sh_degree, campos=cam.camera_center.to(dev),
+        prefiltered=False, debug=True)                      # debug: sync + error check after every kernel
+    color, radii, depth, alpha = GaussianRasterizer(st)(
+        means3D=leaves["means3D"], means2D=m2, opacities=leaves["opacities"], shs=leaves["shs"],
+        scales=leaves["scales"], rotations=leaves["rotations"], cov3D_precomp=leaves["cov3D_precomp"])
+    np.testing.assert_array_equal(radii.cpu().numpy(), ref["geom"].radii)
+    helpers.assert_close_modulo_threshold_flips(color.detach().cpu().numpy(), ref["color"], IMG_TOL)
+    helpers.assert_close_modulo_threshold_flips(alpha.detach().cpu().numpy(), ref["alpha"], IMG_TOL)
+    rng = np.random.default_rng(2)
+    gC, gD, gA = rng.standard_normal((3, H, W)), rng.standard_normal((1, H, W)), rng.standard_normal((1, H, W))
+    gref = ro.render_backward_f64(inp, ref["binning"], W, H, W / (2 * f), H / (2 * f), np.array(bg, np.float64), gC, gD, gA,
+                                  sh_degree=sh_degree, scale_modifier=scale_modifier)
+    tt = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
+    torch.autograd.backward([color, depth, alpha], [tt(gC), tt(gD), tt(gA)])
+    for k in ("means3D", "opacities", "shs", "rotations", "cov3D_precomp", "scales"):
+        if leaves[k] is None or gref.get(k) is None:
+            continue
+        if k == "scales" and scale_modifier != 1.0:
+            continue
+        got = leaves[k].grad.cpu().double().numpy()
+        want = gref[k].reshape(got.shape)
+        scale = np.abs(want).max() + 1e-12
+        assert np.abs(got - want).max() / scale < GRAD_TOL, (k, np.abs(got - want).max() / scale)
+    if sh_coeffs > (sh_degree + 1) ** 2:                  # coefficients above the active degree get exact zeros
+        assert float(leaves["shs"].grad[:, (sh_degree + 1) ** 2:].abs().max()) == 0.0
