@@ -37,11 +37,14 @@ extern "C" {
 int ogs_mask_feature_sums(const float* feat, const uint8_t* masks, const float* weight, int32_t C, int32_t N,
                           int64_t HW, int32_t with_squares, float* table, void* stream);
 
-/* Backward of the mean w.r.t. the feature map:
- *   dfeat[c,pix] = w[pix] * sum_n mask[n,pix] * coef[n,c],   coef = dL/dmean / clamp(count, 1)   ([N,C], host side).
- * Writes every element of dfeat [C,H,W]. */
-int ogs_mask_feature_sums_backward(const uint8_t* masks, const float* weight, const float* coef, int32_t C, int32_t N,
-                                   int64_t HW, float* dfeat, void* stream);
+/* Backward of the sums table, given g = dL/dtable ([N, C+1], host side: coef = g[:, :C] contiguous [N,C],
+ * coef_cnt = g[:, C] contiguous [N]):
+ *   dfeat[c,pix]  = w[pix] * sum_n mask[n,pix] * coef[n,c]                                  (always written)
+ *   dweight[pix]  = sum_n mask[n,pix] * (sum_c coef[n,c] * feat[c,pix] + coef_cnt[n])       (when dweight != NULL;
+ *                   the silhouette passed as image_mask is a rasterizer output, i.e. part of the autograd graph) */
+int ogs_mask_feature_sums_backward(const uint8_t* masks, const float* weight, const float* coef, const float* feat,
+                                   const float* coef_cnt, int32_t C, int32_t N, int64_t HW, float* dfeat,
+                                   float* dweight, void* stream);
 
 /* cohesion_loss pieces: table[n,0] = sum_pix mask[n,pix] * ||feat[:,pix] - mean[n,:]||_2, table[n,1] = pixel count
  * of mask n.  loss = mean_n(table[n,0] / clamp(table[n,1], 1)).  The [N,2] table is zeroed by the call. */

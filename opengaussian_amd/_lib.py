@@ -78,7 +78,7 @@ SIGNATURES = {
                                    _vp, C.c_int64, _vp, _vp]),
     "ogs_kmeans_assign": (C.c_int, [_vp, C.c_int64, C.c_int32, _vp, C.c_int32, _vp, C.c_int64, _vp]),
     "ogs_mask_feature_sums": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int64, C.c_int32, _vp, _vp]),
-    "ogs_mask_feature_sums_backward": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int64, _vp, _vp]),
+    "ogs_mask_feature_sums_backward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int64, _vp, _vp, _vp]),
     "ogs_mask_cohesion": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int64, _vp, _vp]),
     "ogs_mask_cohesion_backward": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int64, _vp, _vp, _vp]),
     "ogs_adam_step": (C.c_int, [C.POINTER(OgsAdamTensor), C.c_int32, C.c_double, C.c_double, C.c_double, _vp]),

@@ -111,17 +111,24 @@ __global__ __launch_bounds__(kBlock) void mask_feature_sums_kernel(const float* 
     });
 }
 
-template <int C, bool VEC>
+// DW: also the gradient w.r.t. the weight map, dweight[pix] = sum_n mask * (sum_c coef[n,c] * feat[c,pix] + coef_cnt[n])
+// (the silhouette the reference passes as image_mask is an output of the rasterizer and so part of the graph).
+template <int C, bool VEC, bool DW>
 __global__ __launch_bounds__(kBlock) void mask_feature_sums_backward_kernel(const uint8_t* __restrict__ masks,
                                                                             const float* __restrict__ weight,
-                                                                            const float* __restrict__ coef, int N,
-                                                                            int64_t HW, float* __restrict__ dfeat) {
+                                                                            const float* __restrict__ coef,
+                                                                            const float* __restrict__ feat,
+                                                                            const float* __restrict__ coef_cnt, int N,
+                                                                            int64_t HW, float* __restrict__ dfeat,
+                                                                            float* __restrict__ dweight) {
     const int64_t i0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kPix;
-    float acc[C][kPix], w[kPix];
+    float acc[C][kPix], w[kPix], accn[kPix];
 #pragma unroll
     for (int c = 0; c < C; ++c)
 #pragma unroll
         for (int j = 0; j < kPix; ++j) acc[c][j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < kPix; ++j) accn[j] = 0.f;
     if (weight) load4<VEC>(weight, i0, HW, w);
     else {
 #pragma unroll
@@ -131,13 +138,29 @@ __global__ __launch_bounds__(kBlock) void mask_feature_sums_backward_kernel(cons
         float cf[C];                                   // wave-uniform row -> scalar loads
 #pragma unroll
         for (int c = 0; c < C; ++c) cf[c] = coef[(size_t)n * C + c];
+        const float cn = DW ? coef_cnt[n] : 0.f;
 #pragma unroll
         for (int j = 0; j < kPix; ++j) {
             const bool in = in_mask(word, j);
 #pragma unroll
             for (int c = 0; c < C; ++c) acc[c][j] += in ? cf[c] : 0.f;
+            if (DW) accn[j] += in ? cn : 0.f;
         }
     });
+    if (DW) {
+        // sum_n mask * sum_c coef[n,c] * f[c]  ==  sum_c f[c] * (sum_n mask * coef[n,c])  ==  sum_c f[c] * acc[c]
+        float dw[kPix];
+#pragma unroll
+        for (int j = 0; j < kPix; ++j) dw[j] = accn[j];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float f[kPix];
+            load4<VEC>(feat + (size_t)c * HW, i0, HW, f);
+#pragma unroll
+            for (int j = 0; j < kPix; ++j) dw[j] += f[j] * acc[c][j];
+        }
+        store4<VEC>(dweight, i0, HW, dw);
+    }
 #pragma unroll
     for (int c = 0; c < C; ++c) {
 #pragma unroll
@@ -279,18 +302,26 @@ int ogs_mask_feature_sums(const float* feat, const uint8_t* masks, const float* 
     return OGS_OK;
 }
 
-int ogs_mask_feature_sums_backward(const uint8_t* masks, const float* weight, const float* coef, int32_t C, int32_t N,
-                                   int64_t HW, float* dfeat, void* stream_) {
+int ogs_mask_feature_sums_backward(const uint8_t* masks, const float* weight, const float* coef, const float* feat,
+                                   const float* coef_cnt, int32_t C, int32_t N, int64_t HW, float* dfeat,
+                                   float* dweight, void* stream_) {
     int rc = check(C, N, HW, masks, coef, dfeat);
     if (rc != OGS_OK) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream_);
     if (HW == 0) return OGS_OK;
     if (!dfeat) { set_error("mask ops: NULL pointer"); return OGS_ERR_INVALID_ARG; }
-    if (N == 0) { OGS_HIP_CHECK(hipMemsetAsync(dfeat, 0, (size_t)C * HW * sizeof(float), s)); return OGS_OK; }
-    const bool vec = vec_ok(HW, dfeat, masks, weight);
-#define CALL(CC, VV)                                                                                                 \
-    OGS_LAUNCH((mask_feature_sums_backward_kernel<CC, VV>), dim3(strips(HW)), dim3(kBlock), 0, s, masks, weight, coef, \
-               N, HW, dfeat)
+    if (dweight && N > 0 && (!feat || !coef_cnt)) { set_error("mask ops: dweight needs feat and coef_cnt"); return OGS_ERR_INVALID_ARG; }
+    if (N == 0) {
+        OGS_HIP_CHECK(hipMemsetAsync(dfeat, 0, (size_t)C * HW * sizeof(float), s));
+        if (dweight) OGS_HIP_CHECK(hipMemsetAsync(dweight, 0, (size_t)HW * sizeof(float), s));
+        return OGS_OK;
+    }
+    const bool vec = vec_ok(HW, dfeat, masks, weight, feat) && vec_ok(HW, dweight, nullptr, nullptr);
+#define CALL(CC, VV)                                                                                                   \
+    if (dweight) OGS_LAUNCH((mask_feature_sums_backward_kernel<CC, VV, true>), dim3(strips(HW)), dim3(kBlock), 0, s,     \
+                            masks, weight, coef, feat, coef_cnt, N, HW, dfeat, dweight);                               \
+    else OGS_LAUNCH((mask_feature_sums_backward_kernel<CC, VV, false>), dim3(strips(HW)), dim3(kBlock), 0, s, masks,    \
+                    weight, coef, feat, coef_cnt, N, HW, dfeat, dweight)
     OGS_MASK_DISPATCH(CALL);
 #undef CALL
     OGS_LAUNCH_CHECK(0, s);

@@ -40,15 +40,6 @@ def _mask_bytes(masks: torch.Tensor) -> torch.Tensor:
     return (masks != 0).to(torch.uint8).contiguous()
 
 
-def _weight_map(image_mask, H, W, dev):
-    if image_mask is None:
-        return None
-    w = image_mask.detach().to(device=dev, dtype=torch.float32)
-    if w.numel() != H * W:
-        raise RuntimeError(f"image_mask must have H*W = {H * W} elements, got {tuple(image_mask.shape)}")
-    return w.reshape(H, W).contiguous()
-
-
 class _MaskSums(torch.autograd.Function):
     """table [N, C+1] (or [N, 2C+1] with squares) of weighted per-mask feature sums | weighted counts."""
 
@@ -58,12 +49,14 @@ class _MaskSums(torch.autograd.Function):
         f = feat_map.detach().to(torch.float32).contiguous()
         C, H, W = (int(x) for x in f.shape)
         N = int(masks_u8.shape[0])
+        w = None if weight is None else weight.detach().to(torch.float32).reshape(H, W).contiguous()
         width = (2 * C + 1) if with_squares else (C + 1)
         table = torch.empty(N, TABLE_STRIDE, dtype=torch.float32, device=f.device)   # 64-byte rows (ogs_mask.h)
-        check(lib.ogs_mask_feature_sums(ptr(f), ptr(masks_u8), ptr(weight), C, N, H * W, int(bool(with_squares)),
+        check(lib.ogs_mask_feature_sums(ptr(f), ptr(masks_u8), ptr(w), C, N, H * W, int(bool(with_squares)),
                                         ptr(table), _stream()), "ogs_mask_feature_sums")
-        ctx.save_for_backward(masks_u8, weight)
+        ctx.save_for_backward(masks_u8, w, f)
         ctx.shape = (C, H, W, N)
+        ctx.weight_shape = None if weight is None else tuple(weight.shape)
         ctx.with_squares = bool(with_squares)
         return table[:, :width]
 
@@ -72,14 +65,20 @@ class _MaskSums(torch.autograd.Function):
         if ctx.with_squares:
             raise RuntimeError("mask_feature_mean(return_var=True) is not differentiable here (the reference only "
                                "uses it under no_grad, train.py:689)")
-        masks_u8, weight = ctx.saved_tensors
+        masks_u8, w, f = ctx.saved_tensors
         C, H, W, N = ctx.shape
-        # d table[n, c] / d feat[c, pix] = mask * w ; the count column does not depend on feat
+        # d table[n, c] / d feat[c, pix] = mask * w ;  d table[n, c] / d w[pix] = mask * feat[c, pix] ;
+        # d table[n, C] / d w[pix] = mask
         coef = g_table[:, :C].to(torch.float32).contiguous()
+        need_w = w is not None and ctx.needs_input_grad[2]
+        coef_cnt = g_table[:, C].to(torch.float32).contiguous() if need_w else None
         dfeat = torch.empty(C, H, W, dtype=torch.float32, device=g_table.device)
-        check(_lib.lib().ogs_mask_feature_sums_backward(ptr(masks_u8), ptr(weight), ptr(coef), C, N, H * W, ptr(dfeat),
-                                                        _stream()), "ogs_mask_feature_sums_backward")
-        return dfeat, None, None, None
+        dweight = torch.empty(H, W, dtype=torch.float32, device=g_table.device) if need_w else None
+        check(_lib.lib().ogs_mask_feature_sums_backward(ptr(masks_u8), ptr(w), ptr(coef), ptr(f), ptr(coef_cnt), C, N,
+                                                        H * W, ptr(dfeat), ptr(dweight), _stream()),
+              "ogs_mask_feature_sums_backward")
+        return (dfeat if ctx.needs_input_grad[0] else None, None,
+                dweight.reshape(ctx.weight_shape) if need_w else None, None)
 
 
 def mask_feature_mean(feat_map, gt_masks, image_mask=None, return_var=False):
@@ -92,10 +91,11 @@ def mask_feature_mean(feat_map, gt_masks, image_mask=None, return_var=False):
     m = _mask_bytes(gt_masks.to(feat_map.device))
     if tuple(m.shape[1:]) != (H, W):
         raise RuntimeError(f"gt_masks must be [num_mask, {H}, {W}], got {tuple(gt_masks.shape)}")
-    w = _weight_map(image_mask, H, W, feat_map.device)
-    if image_mask is not None and image_mask.requires_grad:
-        raise RuntimeError("gradient w.r.t. image_mask is not implemented (the reference's silhouette is detached)")
-    table = _MaskSums.apply(feat_map, m, w, bool(return_var))
+    if image_mask is not None:
+        if image_mask.numel() != H * W:
+            raise RuntimeError(f"image_mask must have H*W = {H * W} elements, got {tuple(image_mask.shape)}")
+        image_mask = image_mask.to(feat_map.device)
+    table = _MaskSums.apply(feat_map, m, image_mask, bool(return_var))
     counts = table[:, C].clamp(min=1)
     mean = table[:, :C] / counts[:, None]
     if not return_var:

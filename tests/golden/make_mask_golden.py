@@ -10,7 +10,7 @@ are compiled one by one from their source text (ast) into a namespace holding on
     train.py:              cohesion_loss, separation_loss
 
 Inputs are regenerated from the seed by ``case_inputs`` (shared with the tests); the file stores the outputs and
-the autograd gradients of the stage-1 loss (train.py:450-456) w.r.t. the feature map.
+the autograd gradients of the stage-1 loss (train.py:450-456) w.r.t. the feature map and the silhouette.
 """
 import ast
 import os
@@ -67,7 +67,8 @@ def main():
         feat, masks, sil, masks2 = case_inputs(seed, C, H, W, N, overlap)
         k = f"s{seed}"
         fm = feat.clone().requires_grad_(True)
-        mean_w = u["mask_feature_mean"](fm, masks, image_mask=sil)
+        sw = sil.clone().requires_grad_(True)        # the silhouette is a rasterizer output: part of the graph
+        mean_w = u["mask_feature_mean"](fm, masks, image_mask=sw)
         coh = t["cohesion_loss"](fm, masks, mean_w)
         sep = t["separation_loss"](mean_w, 1000)
         loss = sep + 0.1 * coh                                           # train.py:456
@@ -76,6 +77,7 @@ def main():
         out[k + "_cohesion"] = np.float32(coh.item())
         out[k + "_separation"] = np.float32(sep.item())
         out[k + "_dfeat"] = fm.grad.numpy()
+        out[k + "_dsil"] = sw.grad.numpy()
         out[k + "_mean"] = u["mask_feature_mean"](feat, masks).numpy()
         mv, var, cnt = u["mask_feature_mean"](feat, masks, return_var=True)
         out[k + "_var"] = var.numpy(); out[k + "_cnt"] = cnt.numpy()

@@ -42,11 +42,14 @@ def test_stage1_loss_gradient_matches_reference(gpu_device, case):
     seed, C, H, W, N, overlap = case
     feat, masks, sil, _ = (t.to(gpu_device) for t in case_inputs(*case))
     fm = feat.clone().requires_grad_(True)
-    mean_w = mk.mask_feature_mean(fm, masks, image_mask=sil)
+    sw = sil.clone().requires_grad_(True)             # the silhouette is a rasterizer output: part of the graph
+    mean_w = mk.mask_feature_mean(fm, masks, image_mask=sw)
     loss = mk.separation_loss(mean_w, 1000) + 0.1 * mk.cohesion_loss(fm, masks, mean_w)
     loss.backward()
     want = GOLD[f"s{seed}_dfeat"]
     assert np.abs(fm.grad.cpu().numpy() - want).max() <= 1e-4 * np.abs(want).max()
+    want = GOLD[f"s{seed}_dsil"]
+    assert np.abs(sw.grad.cpu().numpy() - want).max() <= 1e-4 * np.abs(want).max()
     np.testing.assert_allclose(float(loss.detach()), float(GOLD[f"s{seed}_separation"]) + 0.1 * float(GOLD[f"s{seed}_cohesion"]), rtol=2e-5)
 
 
@@ -76,7 +79,7 @@ def test_full_size_against_oracle(gpu_device, H, W, N, C):
     coh = mk.cohesion_loss(fm, mg, mean)
     (mean.square().sum() + coh).backward()
     np.testing.assert_allclose(mean.detach().cpu().numpy(), mean_ref.detach().numpy(), rtol=3e-5, atol=1e-6)
-    np.testing.assert_allclose(float(coh), float(coh_ref), rtol=3e-5)
+    np.testing.assert_allclose(float(coh.detach()), float(coh_ref.detach()), rtol=3e-5)
     want = fm_ref.grad.numpy()
     assert np.abs(fm.grad.cpu().numpy() - want).max() <= 1e-4 * np.abs(want).max()
     # size-independent property: the masks partition the labelled pixels, so the per-mask weighted sums add up to

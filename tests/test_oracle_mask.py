@@ -37,11 +37,14 @@ def test_oracle_gradient_of_stage1_loss_matches_reference(case):
     seed, C, H, W, N, overlap = case
     feat, masks, sil, _ = case_inputs(*case)
     fm = feat.clone().requires_grad_(True)
-    mean_w = mo.mask_feature_mean(fm, masks, image_mask=sil)
+    sw = sil.clone().requires_grad_(True)
+    mean_w = mo.mask_feature_mean(fm, masks, image_mask=sw)
     loss = separation_loss(mean_w, 1000) + 0.1 * mo.cohesion_loss(fm, masks, mean_w)
     loss.backward()
     want = GOLD[f"s{seed}_dfeat"]
     assert np.abs(fm.grad.numpy() - want).max() <= 2e-5 * np.abs(want).max() + 1e-9
+    want = GOLD[f"s{seed}_dsil"]
+    assert np.abs(sw.grad.numpy() - want).max() <= 2e-5 * np.abs(want).max() + 1e-9
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: f"s{c[0]}")
