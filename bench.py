@@ -363,13 +363,19 @@ def main():
         ab = algorithmic_bytes(P, D, npx, dom_C, {3: 48, 9: 54}.get(dom_C, dom_C))
         dom_bytes = ab.get(dom_base)
         traffic = None
+        hbm_kernels = None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         # the committed counter table was collected on the default workload (S1M-1080p, fused pass)
         if os.path.exists(pmc_file) and args.workload == "S1M-1080p" and fused:
             try:
-                traffic = json.load(open(pmc_file)).get(dom)
+                pmc = json.load(open(pmc_file))
+                traffic = pmc.get(dom)
+                # measured HBM bytes per launch (PMC) / live launch duration, for every kernel of the step
+                hbm_kernels = {k: {"GBps": pmc[k] / (v["avg_ms"] * 1e-3) / 1e9,
+                                   "frac_of_peak": pmc[k] / (v["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+                               for k, v in per_kernel.items() if k in pmc and v["avg_ms"] > 0}
             except Exception:
-                traffic = None
+                traffic, hbm_kernels = None, None
         roofline = None
         if dom_bytes is not None:
             achieved = dom_bytes / (per_kernel[dom]["avg_ms"] * 1e-3) / 1e9
@@ -398,6 +404,7 @@ def main():
                                           if args.exchange == "pipelined" else "")) if world > 1 else "single"},
             "scene": {"P_visible": p_vis, "D_num_rendered": D, "mean_tile_list": D / gxy},
             "roofline": roofline,
+            "pmc_hbm_rate_per_kernel": hbm_kernels,
             "step_algorithmic_GBps": step_bytes / (ms_per_step * 1e-3) / 1e9,
             "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]["total_ms"])},
         }
