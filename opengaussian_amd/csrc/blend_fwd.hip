@@ -225,19 +225,29 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
             if (__ballot(stop) != 0ull) all_done = __ballot(fxe < kFarTest) == 0ull;   // whole wave finished?
         }
     };
-    // software pipeline over the wave-uniform index stream: records of entries j+1 and j+2 are in flight while
-    // entry j is blended, their indices were fetched one iteration earlier (all scalar loads)
+    // Software pipeline over the wave-uniform index stream, in BATCHES of two records.  SMEM returns out of order,
+    // so the only wait there is is lgkmcnt(0) = "everything in flight": a wait placed after a load covers that
+    // load too.  Hence: wait (batch issued two entries ago) -> issue the NEXT batch -> blend two entries.  Every
+    // record load gets two entries' worth of blending to arrive (SQ counters of the one-ahead version: 53 % of the
+    // forward's wave-cycles parked on s_waitcnt).  Four record register sets = 72 SGPRs.
     if (n > 0) {
-        StreamRec<C> recA, recB;
-        uint32_t i1 = qi[1], i2 = qi[2];
-        recA.load(rec_at(qi[0]));
-        for (int j = 0; j < n && !all_done; j += 2) {
-            recB.load(rec_at(i1));
-            const uint32_t n3 = qi[j + 3], n4 = qi[j + 4];
-            consume(recA, j);
-            recA.load(rec_at(i2));
-            if (j + 1 < n) consume(recB, j + 1);
-            i1 = n3; i2 = n4;
+        StreamRec<C> a0, a1, b0, b1;
+        uint32_t i2 = qi[2], i3 = qi[3], i4 = qi[4], i5 = qi[5];
+        a0.load(rec_at(qi[0]));
+        a1.load(rec_at(qi[1]));
+        for (int j = 0; j < n && !all_done; j += 4) {
+            wait_scalar_loads();
+            b0.load(rec_at(i2));
+            b1.load(rec_at(i3));
+            const uint32_t n6 = qi[j + 6], n7 = qi[j + 7], n8 = qi[j + 8], n9 = qi[j + 9];
+            consume(a0, j);
+            if (j + 1 < n) consume(a1, j + 1);
+            wait_scalar_loads();
+            a0.load(rec_at(i4));
+            a1.load(rec_at(i5));
+            if (j + 2 < n) consume(b0, j + 2);
+            if (j + 3 < n) consume(b1, j + 3);
+            i2 = n6; i3 = n7; i4 = n8; i5 = n9;
         }
     }
 

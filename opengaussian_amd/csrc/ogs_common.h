@@ -94,7 +94,7 @@ __host__ __device__ constexpr int stream_vec4(int C) { return (8 + C + 1 + 3) / 
 // region of quadrant q of a tile with list [start, start + n) = quad_list[4*start + q*n ... + n).  The blend
 // loops prefetch two indices past either end of a region (kQuadPad u32 of slack in front and behind) and clamp
 // whatever they read to [0, n-1] before touching a record.
-constexpr int kQuadPad = 8;
+constexpr int kQuadPad = 16;
 template <int C>
 inline float4* stream_base(void* buf) { return static_cast<float4*>(buf); }
 inline uint32_t* quad_base(void* buf) { return static_cast<uint32_t*>(buf) + kQuadPad; }
@@ -261,6 +261,12 @@ int launch_export_keys(const uint2* ranges, int tiles, const uint32_t* point_lis
                        uint64_t* keys_out, hipStream_t s);
 
 // ---- tiny device helpers ------------------------------------------------------------------------
+// s_waitcnt lgkmcnt(0) (vmcnt / expcnt untouched), pinned in place: nothing is scheduled across it
+__device__ __forceinline__ void wait_scalar_loads() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_sched_barrier(0);
+}
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 
 }  // namespace ogs
