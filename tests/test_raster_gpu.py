@@ -440,3 +440,39 @@ def test_sh_degrees_coefficient_counts_and_scale_modifier(gpu_device, sh_degree,
         assert np.abs(got - want).max() / scale < GRAD_TOL, (k, np.abs(got - want).max() / scale)
     if sh_coeffs > (sh_degree + 1) ** 2:                  # coefficients above the active degree get exact zeros
         assert float(leaves["shs"].grad[:, (sh_degree + 1) ** 2:].abs().max()) == 0.0
+
+
+def test_random_configurations_forward_parity(gpu_device):
+    """24 seeded random configurations (image sizes incl. non-multiples of 16 and single-tile images, point counts
+    from 1 to a few thousand, focal lengths, scale / opacity statistics, SH or precomputed colours, covariance
+    input, background): integers bit-exact, images within 1e-4 (modulo documented threshold flips)."""
+    from oracle import raster_oracle as ro
+    rng = np.random.default_rng(2024)
+    for it in range(24):
+        W, H = int(rng.integers(5, 200)), int(rng.integers(5, 140))
+        P = int(rng.choice([1, 2, 7, 63, 64, 65, 300, 1500, 4000]))
+        f = float(rng.uniform(0.4, 1.6) * max(W, H))
+        lsm = float(rng.uniform(-4.5, -1.5))
+        use_sh, use_cov = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        bg = tuple(float(x) for x in rng.uniform(0, 1, 3))
+        sc, cam = helpers.tiny_scene(P, W, H, f, seed=1000 + it, log_scale_mean=lsm, with_ties=bool(it % 3 == 0))
+        if it % 4 == 1:
+            sc.opacities[:] = torch.rand_like(sc.opacities) ** 3          # many near-threshold opacities
+        inp = helpers.oracle_inputs(sc, cam, use_sh=use_sh, use_cov=use_cov)
+        ref = ro.render_forward(W=W, H=H, tanfovx=W / (2 * f), tanfovy=H / (2 * f), bg=np.array(bg, np.float32),
+                                sh_degree=3, **inp)
+        (_c, radii, _d, _a), _ = helpers.hip_forward(inp, cam, bg, 3, gpu_device, requires_grad=True)
+        color, depth, alpha = _c.detach(), _d.detach(), _a.detach()
+        keys, ranges, ncontrib, plist = (helpers.hip_export_binning(_c) if ref["binning"].num_rendered > 0 else (None,) * 4)
+        tag = f"config {it}: {W}x{H} P={P} f={f:.1f} lsm={lsm:.2f} sh={use_sh} cov={use_cov}"
+        np.testing.assert_array_equal(radii.cpu().numpy(), ref["geom"].radii, err_msg=tag)
+        if keys is not None:
+            np.testing.assert_array_equal(keys, ref["binning"].keys_sorted, err_msg=tag)
+            np.testing.assert_array_equal(plist, ref["binning"].point_list, err_msg=tag)
+            np.testing.assert_array_equal(ranges, ref["binning"].ranges, err_msg=tag)
+        try:
+            helpers.assert_close_modulo_threshold_flips(color.cpu().numpy(), ref["color"], IMG_TOL)
+            helpers.assert_close_modulo_threshold_flips(alpha.cpu().numpy(), ref["alpha"], IMG_TOL)
+            helpers.assert_close_modulo_threshold_flips(depth.cpu().numpy(), ref["depth"], IMG_TOL * 10, flip_tol=4e-2)
+        except AssertionError as e:
+            raise AssertionError(f"{tag}: {e}") from None
