@@ -23,8 +23,9 @@ constexpr int kMaxD = OGS_KMEANS_MAX_DIM;
 constexpr int kMaxBlocks = 2048;     // 8 workgroups per CU keep the distance loop's LDS/VALU latency covered
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-// argmin over the first k_active centres of sum_j (x_j - c_j)^2, sequential fp32 accumulation, no FMA
-// (this file is built with -ffp-contract=off: same operation order as oracle/kmeans_oracle.py).
+// argmin over the first k_active centres of sum_j (x_j - c_j)^2, sequential fp32 accumulation in the order of
+// oracle/kmeans_oracle.py (direct differences -- more accurate than the reference's mm-based cdist,
+// scene/kmeans_quantize.py:54); the compile-time-width path fuses each square into the running sum.
 // DT > 0: the feature width is a compile-time constant (6 and 9 are the reference's two codebook levels), so
 // the distance loop is straight-line code; DT == 0: generic width d <= 16.
 template <int DT>
@@ -36,14 +37,18 @@ __device__ __forceinline__ int nearest_centre(const float* __restrict__ rows, in
         float x[DT];
 #pragma unroll
         for (int j = 0; j < DT; ++j) x[j] = rows[row * DT + j];
+        // `cs` is wave-uniform GLOBAL memory here: the centre coordinates arrive through scalar loads and feed the
+        // VALU as SGPR operands (reading them from LDS cost 9 broadcast ds_reads per centre and made the loop
+        // LDS-issue bound); four centres per trip keep four scalar loads in flight
+#pragma unroll 4
         for (int c = 0; c < k_active; ++c) {
             const float* cc = cs + c * DT;
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < DT; ++j) {
                 const float t = x[j] - cc[j];
-                s += t * t;
-            }
+                s = fmaf(t, t, s);             // one rounding per term (the oracle rounds the square separately:
+            }                                  // ids can differ on ties closer than ~1 ulp, see the tests' bar)
             if (s < best) { best = s; best_id = c; }
         }
     } else {
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(kBlock) void kmeans_mfma_pass_kernel(const float* _
         __syncthreads();
         int best_id = -1;
         if (tid < nrows) {
-            best_id = nearest_centre<DT>(rows, tid, d, cs, k_active);
+            best_id = nearest_centre<DT>(rows, tid, d, DT > 0 ? centers : cs, k_active);
             if (!ACCUM) ids_out[row0 + tid] = (int64_t)best_id + id_offset;
         }
         if (ACCUM) {
