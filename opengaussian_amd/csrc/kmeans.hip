@@ -189,7 +189,15 @@ __global__ __launch_bounds__(kBlock) void kmeans_reduce_kernel(const float* __re
     const int per = (nblocks + kSlices - 1) / kSlices;
     const int b0 = blockIdx.y * per, b1 = min(nblocks, b0 + per);
     float s = 0.f;
-    for (int b = b0; b < b1; ++b) s += partials[(size_t)b * stride + e];
+    int b = b0;
+    for (; b + 8 <= b1; b += 8) {                  // block order kept; eight loads in flight
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = partials[(size_t)(b + u) * stride + e];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; b < b1; ++b) s += partials[(size_t)b * stride + e];
     slices[(size_t)blockIdx.y * stride + e] = s;
 }
 
@@ -205,8 +213,17 @@ __global__ __launch_bounds__(1024) void kmeans_finalize_kernel(const float* __re
     extern __shared__ float tot[];            // [k*(d+1)]
     const int stride = k * (d + 1);
     for (int e = threadIdx.x; e < stride; e += blockDim.x) {
+        // fixed summation order, but eight loads in flight (a plain runtime-bound loop ran one L2 round trip per slice)
         float s = 0.f;
-        for (int sl = 0; sl < nslices; ++sl) s += slices[(size_t)sl * stride + e];
+        int sl = 0;
+        for (; sl + 8 <= nslices; sl += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = slices[(size_t)(sl + u) * stride + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; sl < nslices; ++sl) s += slices[(size_t)sl * stride + e];
         tot[e] = s;
         if (table_out) table_out[e] = s;
     }
