@@ -16,8 +16,11 @@ keeps the feature loss out of the geometry gradients, so the gradients equal tho
 tests/test_raster_gpu.py::test_fused_pass_equals_separate_passes).  --separate-passes runs them as two passes
 (3-channel SH + 6-channel), --rgb-only times (A) alone.
 Inputs are resident in HBM before the timed region.  value = views*W*H / time, summed over all ranks
-(weak scaling: rank r renders its own view of the same replicated scene; for N > 1 the per-Gaussian
-gradients are SUM-all-reduced over RCCL inside the step as one flat bucket).
+(weak scaling: rank r renders its own view of the same replicated scene; for N > 1 every step exchanges the
+per-Gaussian gradients over RCCL -- one flat SUM all-reduce + an all-gather of the rank-1 factor of the SH
+gradient + a MAX all-reduce of the radii, opengaussian_amd/dp.py -- by default overlapped with the next view's
+render (--exchange pipelined; every exchange still completes inside the timed region), --exchange sync waits for
+each step's own exchange).
 
 One JSON line on rank 0, with `roofline` (dominant kernel, HIP events on the launch stream, algorithmic
 bytes of SURVEY.md section 8(d)) and `cpu_baseline` (the CPU oracle = pure-PyTorch per-tile alpha blend,
