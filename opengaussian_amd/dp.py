@@ -195,3 +195,98 @@ def shard_views(num_views: int, rank: int, world: int) -> List[int]:
     """Views rendered by `rank` for a mini-batch of `num_views` (round-robin, one view per GPU per step
     when num_views == world)."""
     return [v for v in range(num_views) if v % world == rank]
+
+
+class ShardedAdam:
+    """ZeRO-1 style optimizer state sharding for the replicated-Gaussian data-parallel mode (SURVEY.md section 8(e)
+    "alternative for >= 2 M points", f2): all parameters live in ONE flat fp32 buffer (the tensors handed out are
+    views of it), rank r owns the r-th contiguous slice.  step():
+
+        pack the per-view gradients into a flat buffer
+        reduce-scatter (SUM)            -> this rank's slice of the summed gradient      (RCCL; gloo: all-reduce + slice)
+        fused Adam on the slice         -> ogs_adam_step, one launch; moments exist for the slice only (memory / N)
+        all-gather of the updated slice -> every rank holds the new parameters
+
+    Same bytes on the wire as all-reduce + replicated Adam, 1/N of the optimizer time and state.  Per-parameter
+    learning rates as in the reference's param groups (scene/gaussian_model.py:216-224)."""
+
+    def __init__(self, named_shapes, lrs, device, group=None, betas=(0.9, 0.999), eps=1e-15):
+        self.group = group
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self.names = [n for n, _ in named_shapes]
+        self.shapes = {n: tuple(s) for n, s in named_shapes}
+        self.lrs = dict(lrs)
+        self.betas, self.eps = betas, eps
+        self.offsets, off = {}, 0
+        for n, s in named_shapes:
+            self.offsets[n] = off
+            off += int(torch.Size(s).numel())
+        self.total = off
+        quantum = self.world * 4                                   # slices stay 16-byte aligned
+        self.padded = (off + quantum - 1) // quantum * quantum
+        self.slice = self.padded // self.world
+        self.flat = torch.zeros(self.padded, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(self.padded, dtype=torch.float32, device=device)
+        self.params = {n: self.flat[self.offsets[n]:self.offsets[n] + int(torch.Size(self.shapes[n]).numel())]
+                       .view(self.shapes[n]).requires_grad_(True) for n in self.names}
+        lo = self.rank * self.slice
+        self.my = (lo, lo + self.slice)
+        self.my_grad = torch.zeros(self.slice, dtype=torch.float32, device=device)
+        self.my_param = torch.zeros(self.slice, dtype=torch.float32, device=device)
+        self.exp_avg = torch.zeros(self.slice, dtype=torch.float32, device=device)
+        self.exp_avg_sq = torch.zeros(self.slice, dtype=torch.float32, device=device)
+        self.step_count = 0
+
+    def load(self, tensors: dict):
+        """initial values (identical on every rank)"""
+        with torch.no_grad():
+            for n in self.names:
+                self.params[n].copy_(tensors[n])
+
+    @torch.no_grad()
+    def step(self):
+        from . import _lib
+        from ._lib import OgsAdamTensor
+        for n in self.names:
+            g = self.params[n].grad
+            seg = self.grad[self.offsets[n]:self.offsets[n] + self.params[n].numel()]
+            if g is None:
+                seg.zero_()
+            else:
+                seg.copy_(g.reshape(-1))
+        lo, hi = self.my
+        if self.world > 1:
+            if dist.get_backend(self.group) == "nccl":
+                dist.reduce_scatter_tensor(self.my_grad, self.grad, op=dist.ReduceOp.SUM, group=self.group)
+            else:                                                   # gloo has no reduce-scatter
+                dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.group)
+                self.my_grad.copy_(self.grad[lo:hi])
+        else:
+            self.my_grad.copy_(self.grad[lo:hi])
+        self.my_param.copy_(self.flat[lo:hi])
+        self.step_count += 1
+        descs = []
+        for n in self.names:                                        # this rank's part of every parameter
+            a = max(self.offsets[n], lo)
+            b = min(self.offsets[n] + self.params[n].numel(), hi)
+            if b <= a:
+                continue
+            d = OgsAdamTensor()
+            d.param = self.my_param.data_ptr() + 4 * (a - lo)
+            d.grad = self.my_grad.data_ptr() + 4 * (a - lo)
+            d.exp_avg = self.exp_avg.data_ptr() + 4 * (a - lo)
+            d.exp_avg_sq = self.exp_avg_sq.data_ptr() + 4 * (a - lo)
+            d.numel, d.lr, d.step = b - a, float(self.lrs[n]), self.step_count
+            descs.append(d)
+        if descs:
+            import ctypes as C
+            arr = (OgsAdamTensor * len(descs))(*descs)
+            _lib.check(_lib.lib().ogs_adam_step(arr, len(descs), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                                                torch.cuda.current_stream().cuda_stream), "ogs_adam_step")
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.flat, self.my_param, group=self.group)
+        else:
+            self.flat[lo:hi].copy_(self.my_param)
+        for n in self.names:
+            self.params[n].grad = None
