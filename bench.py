@@ -13,7 +13,7 @@ Workload (BASELINE.json `metric`): synthetic S1M-1080p s
       backward to ins_feat only (stage-1 style: geometry detached, train.py:431-436).
 Default: (A) and (B) are rendered by ONE fused 9-channel rasterizer pass (rasterize_fused; the backward kernel
 keeps the feature loss out of the geometry gradients, so the gradients equal those of two separate passes --
-tests/test_raster_gpu.py::test_fused_pass_equals_separate_passes).  --separate-passes runs them as two passes
+tests/test_10_raster_gpu.py::test_fused_pass_equals_separate_passes).  --separate-passes runs them as two passes
 (3-channel SH + 6-channel), --rgb-only times (A) alone.
 Inputs are resident in HBM before the timed region.  value = views*W*H / time, summed over all ranks
 (weak scaling: rank r renders its own view of the same replicated scene; for N > 1 every step exchanges the

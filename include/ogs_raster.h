@@ -98,7 +98,10 @@ typedef struct OgsRasterFwdArgs {
  * radii, colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix,
  * tan_fovx, tan_fovy, dL_dcolor, dL_ddepth, dL_dalpha, sh, degree, campos, geomBuffer, R,
  * binningBuffer, imgBuffer, alpha, debug).  Any output pointer may be NULL to skip that
- * gradient family (stages 1-2 only need dL_dcolors + dL_dmeans2D). */
+ * gradient family (stages 1-2 only need dL_dcolors).  When dL_dcolors is the ONLY
+ * non-NULL output (every Gaussian parameter but `_ins_feat` detached, train.py:431-436, and the caller does not
+ * consume dL_dmeans2D -- it only feeds densification, train.py:594-598) the pass runs its features-only kernels:
+ * no alpha-gradient recursion, no geometry partials, no per-Gaussian geometry backward. */
 typedef struct OgsRasterBwdArgs {
     int32_t P, W, H, C, sh_degree, sh_coeffs;
     float tanfovx, tanfovy, scale_modifier;
@@ -129,7 +132,10 @@ typedef struct OgsRasterBwdArgs {
     const uint32_t* point_list;
     const void* sorted_rec;      /* from forward */
     const void* quad_list;       /* from forward */
-    void* bwd_tmp;               /* ogs_raster_backward_tmp_bytes(P): zeroed by the call */
+    void* bwd_tmp;               /* ogs_raster_backward_tmp_bytes(P): zeroed by the call.  Holds the per-Gaussian gradient
+                                    record, 16 fp64 running sums = 128 B (float atomics arrive in a different order every
+                                    run; an fp64 sum is order-insensitive to ~1e-16 and is rounded to fp32 once).
+                                    Environment OGS_GRAD_ACCUM=f32 selects 16 fp32 sums (A-B timing only). */
     float* dL_dmeans2D;          /* [P,3] (x,y in NDC units: pixel gradient * 0.5*W / 0.5*H; z = 0) */
     float* dL_dcolors;           /* same shape as colors_precomp: [P,C], or [P,C-3] in a fused SH pass */
     float* dL_dopacity;          /* [P] */
@@ -214,6 +220,8 @@ int ogs_prof_collect(char* buf, size_t n);
 /* Test hook, not part of the reference boundary: runs the wave64 16-slot transposed reduction of the
  * backward blend on in[64][16]; out[lane] = sum over lanes of slot (lane >> 2). */
 int ogs_selftest_wave_fold16(const float* in, float* out, void* stream);
+/* Same for the 8-slot fold of the features-only backward: in[64][8]; out[lane] = sum over lanes of slot (lane >> 3). */
+int ogs_selftest_wave_fold8(const float* in, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,7 @@
 // extern "C" entry points of libogs_hip.so (declared in include/ogs_raster.h).  Host-side
 // orchestration only: argument validation, scratch carving, kernel sequencing on the caller's stream.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -49,6 +50,15 @@ ProfScope::~ProfScope() {
     if (slot < 0) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     (void)hipEventRecord(g_prof[slot].stop, stream);
+}
+
+// OGS_GRAD_ACCUM=f32 selects the fp32 gradient record (diagnostics / A-B timing); default fp64 (ogs_common.h)
+static bool grad_accum_f64() {
+    static const bool v = [] {
+        const char* e = getenv("OGS_GRAD_ACCUM");
+        return !(e && strcmp(e, "f32") == 0);
+    }();
+    return v;
 }
 
 static int bit_length(uint32_t v) {
@@ -150,7 +160,7 @@ size_t ogs_raster_quad_list_bytes(int64_t D) {
     // blend loops' two-ahead index prefetch on either side
     return align_up((size_t)(4 * (D > 0 ? D : 1) + 2 * kQuadPad) * sizeof(uint32_t));
 }
-size_t ogs_raster_backward_tmp_bytes(int32_t P) { return align_up((size_t)(P > 0 ? P : 1) * 16 * sizeof(float)); }
+size_t ogs_raster_backward_tmp_bytes(int32_t P) { return align_up((size_t)(P > 0 ? P : 1) * 16 * sizeof(double)); }
 
 int ogs_raster_forward_geometry(const OgsRasterFwdArgs* a, void* stream_, int64_t* num_rendered_host) {
     int rc = validate_fwd(a);
@@ -253,12 +263,13 @@ int ogs_raster_backward(const OgsRasterBwdArgs* a, void* stream_) {
     const GeomState gs = GeomState::carve(const_cast<void*>(a->geom_buffer), a->P, a->C);
     if (a->num_groups < 0) { set_error("backward: num_groups=%d", a->num_groups); return OGS_ERR_INVALID_ARG; }
     const ImageState is = ImageState::carve(const_cast<void*>(a->image_buffer), a->W, a->H, num_groups_of(a->num_groups));
-    float* grad_rec = static_cast<float*>(a->bwd_tmp);
-    OGS_HIP_CHECK(hipMemsetAsync(grad_rec, 0, (size_t)a->P * grad_stride(a->C) * sizeof(float), s));
+    void* grad_rec = a->bwd_tmp;
+    const bool f64 = grad_accum_f64();
+    OGS_HIP_CHECK(hipMemsetAsync(grad_rec, 0, (size_t)a->P * grad_stride(a->C) * (f64 ? sizeof(double) : sizeof(float)), s));
     if (a->num_rendered > 0 && (!a->sorted_rec || !a->quad_list)) { set_error("backward: sorted_rec / quad_list == NULL"); return OGS_ERR_INVALID_ARG; }
-    int rc = launch_blend_backward(*a, is, grad_rec, s);
+    int rc = launch_blend_backward(*a, is, grad_rec, f64, s);
     if (rc != OGS_OK) return rc;
-    return launch_preprocess_backward(*a, gs, grad_rec, s);
+    return launch_preprocess_backward(*a, gs, grad_rec, f64, s);
 }
 
 int ogs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float*, uint8_t* present,
@@ -285,6 +296,11 @@ int ogs_sh_grad_from_views(int32_t P, int32_t V, int32_t sh_degree, int32_t sh_c
 int ogs_selftest_wave_fold16(const float* in, float* out, void* stream_) {
     if (!in || !out) { set_error("selftest: NULL pointer"); return OGS_ERR_INVALID_ARG; }
     return launch_wave_fold16_test(in, out, static_cast<hipStream_t>(stream_));
+}
+
+int ogs_selftest_wave_fold8(const float* in, float* out, void* stream_) {
+    if (!in || !out) { set_error("selftest: NULL pointer"); return OGS_ERR_INVALID_ARG; }
+    return launch_wave_fold8_test(in, out, static_cast<hipStream_t>(stream_));
 }
 
 int ogs_raster_export_binning(const OgsRasterFwdArgs* a, int64_t D, uint64_t* keys_out, uint32_t* ranges_out,

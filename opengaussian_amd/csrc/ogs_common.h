@@ -250,12 +250,24 @@ int launch_tile_ranges(const uint32_t* tile_keys_sorted, int64_t D, uint2* range
 inline int num_groups_of(int g) { return g > 1 ? g : 1; }
 int launch_blend_forward(const OgsRasterFwdArgs& a, const GeomState& gs, const ImageState& is, int64_t D,
                          hipStream_t s);
-int launch_blend_backward(const OgsRasterBwdArgs& a, const ImageState& is, float* grad_rec, hipStream_t s);
-int launch_preprocess_backward(const OgsRasterBwdArgs& a, const GeomState& gs, const float* grad_rec,
+// The per-Gaussian gradient record is accumulated either in fp32 (64 B) or in fp64 (128 B = one L2 line; the
+// default): with thousands of float atomics per large Gaussian, arriving in a different order every run and
+// cancelling against each other, an fp32 running sum made the gradients differ run to run by ~1e-4 of their
+// maximum (GPUTEST_r01: rotations at S1M); the fp64 sum is order-insensitive to ~1e-16 and is rounded to fp32
+// ONCE, in preprocess_backward_kernel.
+int launch_blend_backward(const OgsRasterBwdArgs& a, const ImageState& is, void* grad_rec, bool f64, hipStream_t s);
+int launch_preprocess_backward(const OgsRasterBwdArgs& a, const GeomState& gs, const void* grad_rec, bool f64,
                                hipStream_t s);
+// Only dL/dcolors_precomp is requested (every other output pointer NULL): the stage >= 1 training graph
+// (train.py:431-436) -> features-only kernels.
+inline bool backward_is_features_only(const OgsRasterBwdArgs& a) {
+    return a.dL_dcolors != nullptr && a.colors_precomp != nullptr && !a.dL_dmeans2D && !a.dL_dopacity &&
+           !a.dL_dmeans3D && !a.dL_dcov3D && !a.dL_dsh && !a.dL_dscales && !a.dL_drotations && !a.dL_dsh_rgb;
+}
 int launch_sh_grad_from_views(int P, int V, int sh_degree, int sh_coeffs, const float* means3D, const float* campos,
                               const float* dL_drgb, float* dL_dsh, hipStream_t s);
 int launch_wave_fold16_test(const float* in, float* out, hipStream_t s);
+int launch_wave_fold8_test(const float* in, float* out, hipStream_t s);
 int launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
 int launch_export_keys(const uint2* ranges, int tiles, const uint32_t* point_list, const float4* rec, int recv4,
                        uint64_t* keys_out, hipStream_t s);

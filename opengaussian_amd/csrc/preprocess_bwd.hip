@@ -21,13 +21,13 @@ __device__ constexpr float kC3[7] = {-0.5900435899266435f, 2.890611442640554f, -
                                      0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
                                      -0.5900435899266435f};
 
-template <int C>
+template <int C, typename ACC>
 __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
     int P, int W, int H, int sh_degree, int sh_coeffs, float tanfovx, float tanfovy, float focal_x, float focal_y,
     float scale_modifier, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
     const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
-    const int32_t* __restrict__ radii, const uint32_t* __restrict__ clamped_in, const float* __restrict__ grad_rec,
+    const int32_t* __restrict__ radii, const uint32_t* __restrict__ clamped_in, const ACC* __restrict__ grad_rec,
     float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
     float* __restrict__ dL_dscales, float* __restrict__ dL_drotations, float* __restrict__ dL_dsh_rgb) {
@@ -37,7 +37,15 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
     const bool vis = radii[idx] > 0;
 
     float gr[16];
-    {
+    if constexpr (sizeof(ACC) == 8) {
+        // fp64 running sums, rounded to fp32 once, here
+        const double2* g2 = reinterpret_cast<const double2*>(grad_rec + (size_t)idx * GS);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const double2 t = vis ? g2[k] : make_double2(0.0, 0.0);
+            gr[2 * k] = (float)t.x; gr[2 * k + 1] = (float)t.y;
+        }
+    } else {
         const float4* g4 = reinterpret_cast<const float4*>(grad_rec + (size_t)idx * GS);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -288,16 +296,16 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
     }
 }
 
-template <int C>
-int launch_c(const OgsRasterBwdArgs& a, const GeomState& gs, const float* grad_rec, hipStream_t s) {
+template <int C, typename ACC>
+int launch_c(const OgsRasterBwdArgs& a, const GeomState& gs, const void* grad_rec, hipStream_t s) {
     const float focal_x = (float)a.W / (2.0f * a.tanfovx);
     const float focal_y = (float)a.H / (2.0f * a.tanfovy);
     const int grid = (a.P + kBlock - 1) / kBlock;
     static constexpr const char* const kNames[4] = {"preprocess_backward_kernel<3>", "preprocess_backward_kernel<6>", "preprocess_backward_kernel<9>", "preprocess_backward_kernel<12>"};
-    OGS_LAUNCH_NAMED(chan_name<C>(kNames), preprocess_backward_kernel<C>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, a.sh_degree,
+    OGS_LAUNCH_NAMED(chan_name<C>(kNames), (preprocess_backward_kernel<C, ACC>), dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, a.sh_degree,
                        a.sh_coeffs, a.tanfovx, a.tanfovy, focal_x, focal_y, a.scale_modifier, a.means3D, a.shs, a.scales,
                        a.rotations, a.cov3D_precomp, a.viewmatrix, a.projmatrix, a.campos, a.radii,
-                       (const uint32_t*)gs.clamped, grad_rec, a.dL_dmeans2D, a.dL_dcolors, a.dL_dopacity, a.dL_dmeans3D,
+                       (const uint32_t*)gs.clamped, (const ACC*)grad_rec, a.dL_dmeans2D, a.dL_dcolors, a.dL_dopacity, a.dL_dmeans3D,
                        a.dL_dcov3D, a.dL_dsh, a.dL_dscales, a.dL_drotations, a.dL_dsh_rgb);
     OGS_LAUNCH_CHECK(a.debug, s);
     return OGS_OK;
@@ -375,12 +383,12 @@ int launch_sh_grad_from_views(int P, int V, int sh_degree, int sh_coeffs, const 
     return OGS_OK;
 }
 
-int launch_preprocess_backward(const OgsRasterBwdArgs& a, const GeomState& gs, const float* grad_rec, hipStream_t s) {
+int launch_preprocess_backward(const OgsRasterBwdArgs& a, const GeomState& gs, const void* grad_rec, bool f64, hipStream_t s) {
     if (a.P <= 0) return OGS_OK;
     switch (a.C) {
-        case 3: return launch_c<3>(a, gs, grad_rec, s);
-        case 6: return launch_c<6>(a, gs, grad_rec, s);
-        case 9: return launch_c<9>(a, gs, grad_rec, s);
+        case 3: return f64 ? launch_c<3, double>(a, gs, grad_rec, s) : launch_c<3, float>(a, gs, grad_rec, s);
+        case 6: return f64 ? launch_c<6, double>(a, gs, grad_rec, s) : launch_c<6, float>(a, gs, grad_rec, s);
+        case 9: return f64 ? launch_c<9, double>(a, gs, grad_rec, s) : launch_c<9, float>(a, gs, grad_rec, s);
         default: set_error("backward: unsupported channel count C=%d", a.C); return OGS_ERR_UNSUPPORTED;
     }
 }

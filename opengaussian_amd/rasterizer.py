@@ -24,6 +24,9 @@ from . import _lib
 from ._lib import OgsRasterBwdArgs, OgsRasterFwdArgs, check, ptr
 
 SUPPORTED_CHANNELS = (3, 6, 9, 12)
+BACKWARD_CHANNELS = (3, 6, 9)          # the gradient record holds C + 7 <= 16 slots
+# diagnostics (scripts/diag_repeat.py): when set to a list, every backward appends its raw gradient-record buffer
+_DEBUG_KEEP_BWD_TMP = None
 # (P, W, H) -> num_rendered of the last pass at that size: capacity hint of the sync-free render phase
 _LAST_NUM_RENDERED: dict = {}
 
@@ -112,6 +115,10 @@ class _RasterizeGaussians(torch.autograd.Function):
             Cn = 3 if cols is None else int(cols.shape[1])
         if Cn not in SUPPORTED_CHANNELS:
             raise RuntimeError(f"the blended channel count must be 3, 6, 9 or 12, got {Cn}")
+        if Cn not in BACKWARD_CHANNELS and any(ctx.needs_input_grad[:8]):
+            # fail here, not in the middle of loss.backward()
+            raise RuntimeError(f"a {Cn}-channel pass is forward-only (backward supports {BACKWARD_CHANNELS} channels): "
+                               "detach the inputs or split the pass")
         bg = _f32c(rs.bg.to(dev))
         if bg is None or bg.numel() != Cn:
             if bg is not None and bg.numel() == 3 and Cn > 3:
@@ -256,6 +263,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         b.dL_dcov3D, b.dL_dsh, b.dL_dscales, b.dL_drotations = ptr(g_cov), ptr(g_sh), ptr(g_scl), ptr(g_rot)
         b.dL_dsh_rgb = ptr(g_sh_rgb)
         check(lib.ogs_raster_backward(C.byref(b), _stream()), "ogs_raster_backward")
+        if _DEBUG_KEEP_BWD_TMP is not None:
+            _DEBUG_KEEP_BWD_TMP.append(bwd_tmp)
         if sink is not None:
             sink.append(g_sh_rgb)
         return g_m3, g_m2, g_sh, g_col, g_op, g_scl, g_rot, g_cov, None, None, None, None, None

@@ -100,8 +100,14 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, iteration,
            cluster_idx=None, leaf_cluster_idx=None, rescale=True, origin_feat=False,
            render_feat_map=True, render_color=True, render_cluster=False, better_vis=False,
            selected_root_id=None, selected_leaf_id=None, pre_mask=None, seg_rgb=False,
-           post_process=False, root_num=64, leaf_num=10):
-    """Render the scene.  Background tensor (bg_color) must be on GPU!"""
+           post_process=False, root_num=64, leaf_num=10, viewspace_grad=None):
+    """Render the scene.  Background tensor (bg_color) must be on GPU!
+
+    viewspace_grad (extension; the reference has no such flag): whether ``viewspace_points.grad`` (dL/dmeans2D) is
+    wanted.  Its only consumer is densification (train.py:594-598, stage 0).  None = automatic: True while any
+    geometry tensor requires grad, False once they are all detached (train.py:431-436) -- the rasterizer then
+    runs its features-only backward (only dL/d ins_feat, no alpha-gradient recursion); ``viewspace_points`` is
+    still returned, its ``.grad`` stays None.  Pass True to force the reference's behaviour."""
     xyz = pc.get_xyz
     dev = xyz.device
     screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=dev) + 0
@@ -130,6 +136,11 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, iteration,
         scales = pc.get_scaling
         rotations = pc.get_rotation
 
+    if viewspace_grad is None:
+        viewspace_grad = any(t is not None and t.requires_grad for t in (means3D, opacity, scales, rotations, cov3D_precomp))
+    if not viewspace_grad:
+        means2D = screenspace_points.detach()
+
     shs = colors_precomp = None
     if override_color is None:
         if pipe.convert_SHs_python:
@@ -154,7 +165,13 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, iteration,
     ins_feat = None
     if render_feat_map:
         ins_feat = (pc.get_ins_feat(origin=origin_feat) + 1) / 2
-    can_fuse = (render_color and render_feat_map and not rescaled and ins_feat.shape[-1] in (3, 6, 9))
+    # a 12-channel pass has no backward (gradient record: C + 7 <= 16 slots): only fuse / widen that far without grad
+    differentiable = torch.is_grad_enabled() and any(
+        t is not None and t.requires_grad for t in (means3D, means2D, opacity, scales, rotations, cov3D_precomp, shs,
+                                                    colors_precomp, ins_feat))
+    max_pass_channels = 9 if differentiable else 12
+    can_fuse = (render_color and render_feat_map and not rescaled and ins_feat.shape[-1] in (3, 6, 9)
+                and ins_feat.shape[-1] + 3 <= max_pass_channels)
     if can_fuse:
         # RGB + features + silhouette on identical geometry: one bin / sort / blend for everything
         if shs is not None:
@@ -174,7 +191,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, iteration,
                 scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
         if render_feat_map:
             # `scales * rescale_factor` with scales=None (compute_cov3D_python) raises, as in the reference (:135)
-            if ins_feat.shape[-1] in (3, 6, 9, 12):
+            if ins_feat.shape[-1] in (3, 6, 9, 12) and ins_feat.shape[-1] <= max_pass_channels:
                 rendered_ins_feat, _, _, silhouette = rasterizer(
                     means3D=means3D, means2D=means2D, shs=None, colors_precomp=ins_feat, opacities=opacity,
                     scales=scales * rescale_factor, rotations=rotations, cov3D_precomp=cov3D_precomp)

@@ -5,7 +5,7 @@ import torch
 sys.path.insert(0, ".")
 from opengaussian_amd import renderer as R
 from opengaussian_amd.synthetic import make_scene, make_camera
-from tests.test_render_gpu import FakeGaussians
+from tests.test_11_render_gpu import FakeGaussians
 
 dev = torch.device("cuda:0")
 P, W, H, f = 2_000_000, 648, 484, 500.0

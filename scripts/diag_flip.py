@@ -2,7 +2,7 @@
 import sys, numpy as np, torch
 sys.path.insert(0, ".")
 from tests import helpers
-from tests.test_raster_gpu import _adversarial_scene
+from tests.test_10_raster_gpu import _adversarial_scene
 from oracle import raster_oracle as ro
 kind, P, W, H = "depth_ties", 2500, 128, 96
 f = 70.0

@@ -68,6 +68,74 @@ def test_wave_fold16(gpu_device):
         torch.testing.assert_close(out.cpu(), expect, rtol=1e-5, atol=1e-4)
 
 
+def test_wave_fold8(gpu_device):
+    from opengaussian_amd import _lib
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(64, 8, generator=g)
+    xi = (torch.arange(64)[:, None] * 13 + torch.arange(8)[None, :] * 5 + 1).float()
+    for inp in (x, xi):
+        d = inp.to(gpu_device).contiguous()
+        out = torch.zeros(64, device=gpu_device)
+        _lib.check(_lib.lib().ogs_selftest_wave_fold8(d.data_ptr(), out.data_ptr(), 0), "selftest")
+        torch.cuda.synchronize()
+        expect = inp.double().sum(0)[torch.arange(64) // 8].float()
+        torch.testing.assert_close(out.cpu(), expect, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("mode", ["feat3", "feat6", "fused9", "grouped6"])
+def test_features_only_backward(gpu_device, mode):
+    """Stage >= 1 training graph (train.py:431-436): every Gaussian parameter but ins_feat is detached and nothing
+    consumes dL/dmeans2D -> the pass runs its features-only backward kernels.  dL/d ins_feat must equal (a) the
+    float64 autograd oracle and (b) what the full backward produces for the same inputs."""
+    from oracle import raster_oracle as ro
+    from opengaussian_amd.rasterizer import GaussianRasterizer, rasterize_fused, rasterize_groups
+    P, W, H, f = 2200, 150, 100, 110.0
+    sc, cam = helpers.tiny_scene(P, W, H, f, seed=77)
+    dev = gpu_device
+    Cf = 3 if mode == "feat3" else 6
+    feat_cpu = sc.ins_feat[:, :Cf].contiguous()
+    bgc = (0.3, 0.1, 0.2)
+    rs = helpers.settings_for(cam, bgc, 3, dev)
+    rng = np.random.default_rng(5)
+    d = lambda t: t.to(dev)
+
+    def run(full):
+        feat = d(feat_cpu).clone().requires_grad_(True)
+        geo = {k: d(getattr(sc, k)).clone().requires_grad_(full) for k in ("means3D", "opacities", "scales", "rotations")}
+        m2 = torch.zeros(P, 3, device=dev, requires_grad=full)
+        if mode == "fused9":
+            shs = d(sc.shs).clone().requires_grad_(full)
+            color, _, _, _ = rasterize_fused(geo["means3D"], m2, geo["opacities"], shs, feat, rs, scales=geo["scales"],
+                                             rotations=geo["rotations"], detach_extra_from_geometry=False)
+        elif mode == "grouped6":
+            ids = (torch.arange(P, device=dev) % 4) - 1          # -1: in no group; 3 groups
+            color, _, _, _ = rasterize_groups(geo["means3D"], m2, geo["opacities"], ids, 3, rs, colors_precomp=feat,
+                                              scales=geo["scales"], rotations=geo["rotations"])
+        else:
+            color, _, _, _ = GaussianRasterizer(rs)(means3D=geo["means3D"], means2D=m2, opacities=geo["opacities"],
+                                                    colors_precomp=feat, scales=geo["scales"], rotations=geo["rotations"])
+        gC = torch.tensor(np.random.default_rng(5).standard_normal(tuple(color.shape)), dtype=torch.float32, device=dev)
+        if mode == "fused9" and not full:
+            gC[:3] = 0                                           # (RGB loss has no path to ins_feat either way)
+        color.backward(gC)
+        return feat.grad, gC, m2.grad
+
+    g_feat, gC, m2g = run(full=False)
+    assert m2g is None
+    g_full, _, m2g_full = run(full=True)
+    assert m2g_full is not None
+    scale = float(g_full.abs().max())
+    assert float((g_feat - g_full).abs().max()) / scale < 2e-5, mode
+    if mode in ("feat3", "feat6"):
+        inp = helpers.oracle_inputs(sc, cam, feat=feat_cpu)
+        bg = np.array((bgc * 2)[:Cf], np.float32)
+        ref = ro.render_forward(W=W, H=H, tanfovx=W / (2 * f), tanfovy=H / (2 * f), bg=bg, sh_degree=3, **inp)
+        gref = ro.render_backward_f64(inp, ref["binning"], W, H, W / (2 * f), H / (2 * f), bg.astype(np.float64),
+                                      gC.cpu().double().numpy(), np.zeros((1, H, W)), np.zeros((1, H, W)), sh_degree=3)
+        want = gref["colors_precomp"].reshape(P, Cf)
+        assert np.abs(g_feat.cpu().double().numpy() - want).max() / np.abs(want).max() < 1e-4
+
+
 def test_sh_path_equals_precomputed_colors(gpu_device):
     """gaussian_renderer/__init__.py:92-97: rasterizer SH path == colors_precomp = clamp_min(eval_sh + 0.5, 0)."""
     from oracle import raster_oracle as ro

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from tests import helpers
-from tests.test_render_gpu import FakeGaussians
+from tests.test_11_render_gpu import FakeGaussians
 
 pytestmark = pytest.mark.gpu
 
