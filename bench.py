@@ -41,13 +41,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~6300 achievable
+# VALU issue peak: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles per SIMD, 2.4 GHz
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 4
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--views", type=int, default=8,
+                    help="cameras of the orbit the steps cycle through (multi-view training: num_rendered changes from "
+                         "step to step, so the sync-free render phase's capacity hint is exercised); 1 = the same view "
+                         "every step")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the untimed extra measurements (stage-1 features-only pass, per-kernel breakdown pass)")
     ap.add_argument("--workload", default="S1M-1080p", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tile-stride", type=int, default=8, help="CPU baseline renders this many full tile rows")
@@ -168,6 +176,59 @@ def kmeans_bench(device):
             "algorithmic_GBps": bytes_iter * iters / dt / 1e9}
 
 
+def kmeans_cpu_baseline():
+    """The k-means oracle (NumPy restatement of scene/kmeans_quantize.py:146-241, pinned by the reference goldens) on
+    a bounded sample: N = 200k rows of the same distribution, d = 9, k = 64, 5 Lloyd iterations."""
+    import numpy as np
+    from oracle import kmeans_oracle as ko
+    g = torch.Generator().manual_seed(0)
+    N, k, iters = 200_000, 64, 5
+    feat = torch.cat([torch.rand(N, 6, generator=g), torch.randn(N, 3, generator=g)], dim=1).numpy()
+    cent = feat[:k].copy()
+    t0 = time.time()
+    ko.lloyd(feat, cent, iters=iters, nchunks=N // 10000 + 1)
+    dt = time.time() - t0
+    return {"value": iters / dt, "unit": "Lloyd it/s", "cores": 1, "kind": "port",
+            "sample": f"oracle/kmeans_oracle.py lloyd, N={N} (1/10 of the GPU workload's rows), d=9, k={k}, {iters} iterations "
+                      f"+ re-assignment in {dt:.2f} s; per-row cost is size independent, so the 2M-row rate is ~1/10 of this"}
+
+
+def stage1_bench(leaves, all_settings, gF, P, device, reps=40):
+    """Stage >= 1 training step of the reference (train.py:431-436: everything but ins_feat detached): RGB + 6-D
+    ins_feat + silhouette in ONE fused 9-channel forward, features-only backward (dL/d ins_feat alone).  Untimed
+    extra; reported beside the headline (which is the all-gradient stage-0 style step)."""
+    from opengaussian_amd import _lib
+    from opengaussian_amd.rasterizer import rasterize_fused
+    det = {k: v.detach() for k, v in leaves.items()}
+    feat = leaves["ins_feat"].detach().clone().requires_grad_(True)
+    gC9 = torch.cat([torch.zeros(3, *gF.shape[1:], device=device), gF])
+
+    def one(i):
+        m2 = torch.zeros(P, 3, device=device)                     # no grad: nothing consumes dL/dmeans2D after stage 0
+        color, radii, depth, alpha = rasterize_fused(det["means3D"], m2, det["opacities"], det["shs"], feat,
+                                                     all_settings[i % len(all_settings)], scales=det["scales"],
+                                                     rotations=det["rotations"])
+        feat.grad = None
+        color.backward(gC9)
+    for i in range(5):
+        one(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(reps):
+        one(i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    _lib.prof_enable(1)
+    for i in range(10):
+        one(i)
+    torch.cuda.synchronize()
+    prof = _lib.prof_collect()
+    _lib.prof_enable(0)
+    W, H = gF.shape[2], gF.shape[1]
+    return {"ms_per_step": dt * 1e3, "Mpix_per_s": W * H / dt / 1e6,
+            "kernels_ms": {k: v["total_ms"] / v["calls"] for k, v in prof.items() if "backward" in k or "blend" in k}}
+
+
 _T0 = time.time()
 
 
@@ -181,6 +242,7 @@ def main():
     args = parse()
     log("start")
     from opengaussian_amd import _lib, dp
+    from opengaussian_amd import rasterizer as R
     from opengaussian_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_fused
     from opengaussian_amd.synthetic import make_scene, orbit_camera
 
@@ -197,14 +259,27 @@ def main():
     P, W, H, f = wl["P"], wl["W"], wl["H"], wl["f"]
     scene_cpu = make_scene(P, W, H, f, f, seed=0)
     log(f"scene built: P={P} {W}x{H}")
-    cam_cpu = orbit_camera(W, H, f, f, view_index=rank, num_views=max(world, 1))
-    scene, cam = scene_cpu.to(device), cam_cpu.to(device)
-    tanx, tany = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
-    settings = GaussianRasterizationSettings(
-        image_height=H, image_width=W, tanfovx=tanx, tanfovy=tany, bg=torch.zeros(3, device=device),
-        scale_modifier=1.0, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, sh_degree=3,
-        campos=cam.camera_center, prefiltered=False, debug=False)
-    rast = GaussianRasterizer(settings)
+    # step i of rank r renders view (i * world + r) mod V of a fan of V cameras about the scene centre (view 0 = the
+    # identity camera of SURVEY.md section 8(d)): every rank a different view every step, as in multi-view training
+    V = max(args.views, world, 1)
+    cams_cpu = [orbit_camera(W, H, f, f, view_index=v, num_views=V) for v in range(V)]
+    cam_cpu = cams_cpu[0]
+    scene = scene_cpu.to(device)
+    bg0 = torch.zeros(3, device=device)
+
+    def settings_of(c):
+        c = c.to(device)
+        return GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=math.tan(c.FoVx * 0.5), tanfovy=math.tan(c.FoVy * 0.5), bg=bg0,
+            scale_modifier=1.0, viewmatrix=c.world_view_transform, projmatrix=c.full_proj_transform, sh_degree=3,
+            campos=c.camera_center, prefiltered=False, debug=False)
+    all_settings = [settings_of(c) for c in cams_cpu]
+    campos_views = torch.stack([c.camera_center for c in cams_cpu]).to(device)
+    dist_on = world > 1 or dp.FORCE_COLLECTIVES
+    info = {"i": 0, "D_seen": []}
+
+    def view_of(step_index, r):
+        return (step_index * world + r) % V
 
     leaves = dict(means3D=scene.means3D, scales=scene.scales, rotations=scene.rotations, opacities=scene.opacities,
                   shs=scene.shs, ins_feat=scene.ins_feat)
@@ -216,29 +291,25 @@ def main():
     gF = torch.randn(6, H, W, generator=gen).to(device)
 
     names_a = ["means3D", "scales", "rotations", "opacities", "shs"]
-    bucket_a = dp.GradBucket([leaves[n].shape for n in names_a], device) if world > 1 else None
-    bucket_b = dp.GradBucket([leaves["ins_feat"].shape], device) if world > 1 and not args.rgb_only else None
-    info = {}
+    bucket_a = dp.GradBucket([leaves[n].shape for n in names_a], device) if dist_on else None
+    bucket_b = dp.GradBucket([leaves["ins_feat"].shape], device) if dist_on and not args.rgb_only else None
 
     names_f = names_a + ["ins_feat"]
     fused = not (args.separate_passes or args.rgb_only)
     # N > 1 exchange per step (dp.py): ONE flat SUM bucket (per-Gaussian gradients + the two SUM-reducible
     # densification statistics), an all-gather of the [P,3] rank-1 factor of the SH gradient (rebuilt locally by
     # ogs_sh_grad_from_views: 4x fewer xGMI bytes than all-reducing [P,16,3]), and a MAX all-reduce of the radii.
-    compress_sh = world > 1 and fused and not args.dense_sh_allreduce
+    compress_sh = dist_on and fused and not args.dense_sh_allreduce
     names_x = [n for n in names_f if not (compress_sh and n == "shs")]
     nsets = 2 if args.exchange == "pipelined" else 1
     sets = []
-    if world > 1 and fused:
+    if dist_on and fused:
         for _ in range(nsets):
             sets.append(dict(bucket=dp.GradBucket([leaves[n].shape for n in names_x] + [(2, P)], device, average=False),
                              sh=dp.ShGradExchange(P, 16, device) if compress_sh else None,
                              dsh=torch.empty(P, 16, 3, device=device) if compress_sh else None,
-                             pending=False, radii_work=None))
-        campos_all = torch.stack([orbit_camera(W, H, f, f, view_index=r, num_views=world).camera_center
-                                  for r in range(world)]).to(device)
+                             pending=False, radii_work=None, campos=None))
     gCF = torch.cat([gC, gF])
-    info["i"] = 0
 
     def finish(st):
         """make the reduced gradients of one exchange ready on the compute stream (what an optimizer would read)"""
@@ -246,7 +317,7 @@ def main():
             return
         st["bucket"].wait()
         if st["sh"] is not None:
-            st["sh"].rebuild(leaves["means3D"], campos_all, 3, out=st["dsh"])
+            st["sh"].rebuild(leaves["means3D"], st["campos"], 3, out=st["dsh"])
         if st["radii_work"] is not None:
             st["radii_work"].wait()
         st["pending"] = False
@@ -258,15 +329,18 @@ def main():
             v.grad = None
         m2 = torch.zeros(P, 3, device=device, requires_grad=True)
         sink = [] if compress_sh else None
+        i = info["i"]
+        info["i"] = i + 1
         color, radii, depth, alpha = rasterize_fused(leaves["means3D"], m2, leaves["opacities"], leaves["shs"],
-                                                     leaves["ins_feat"], settings, scales=leaves["scales"],
-                                                     rotations=leaves["rotations"], sh_rgb_sink=sink)
+                                                     leaves["ins_feat"], all_settings[view_of(i, rank)],
+                                                     scales=leaves["scales"], rotations=leaves["rotations"],
+                                                     sh_rgb_sink=sink)
         info["D"] = color.grad_fn.num_rendered
+        info["D_seen"].append(info["D"])
         torch.autograd.backward([color, alpha], [gCF, gA])
         if sets:
-            i = info["i"]
-            info["i"] = i + 1
             st = sets[i % nsets]
+            st["campos"] = campos_views[[view_of(i, r) for r in range(world)]]
             st["bucket"].pack([leaves[n].grad for n in names_x] + [dp.densification_stats(m2.grad, radii)])
             st["bucket"].allreduce_async()                               # RCCL, side stream
             if st["sh"] is not None:
@@ -287,10 +361,14 @@ def main():
             return step_fused()
         for v in leaves.values():
             v.grad = None
+        i = info["i"]
+        info["i"] = i + 1
+        rast = GaussianRasterizer(all_settings[view_of(i, rank)])
         m2a = torch.zeros(P, 3, device=device, requires_grad=True)
         color, radii, depth, alpha = rast(means3D=leaves["means3D"], means2D=m2a, opacities=leaves["opacities"],
                                           shs=leaves["shs"], scales=leaves["scales"], rotations=leaves["rotations"])
         info["D"] = color.grad_fn.num_rendered
+        info["D_seen"].append(info["D"])
         torch.autograd.backward([color, alpha], [gC, gA])
         if bucket_a is not None:
             bucket_a.pack([leaves[n].grad for n in names_a])
@@ -304,7 +382,7 @@ def main():
             if bucket_b is not None:
                 bucket_b.pack([leaves["ins_feat"].grad])
                 bucket_b.allreduce_async()
-        if world > 1:
+        if dist_on:
             dp.reduce_densification_stats(m2a.grad, radii)
             bucket_a.wait()
             if bucket_b is not None:
@@ -312,7 +390,7 @@ def main():
         return radii
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -326,6 +404,8 @@ def main():
     # serialises the queue for ~10 us per launch, and a step issues ~50 launches, so bracketing every kernel
     # inside the timed region would cost ~0.5 ms/step.  The dominant kernel (roofline) is a blend kernel.
     _lib.prof_enable(2)
+    stats0 = dict(R.PASS_STATS)
+    info["D_seen"] = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         radii = step()
@@ -335,16 +415,20 @@ def main():
     elapsed = time.perf_counter() - t0
     log(f"timed region done: {elapsed / args.steps * 1e3:.3f} ms/step")
     prof = _lib.prof_collect()
-    # second, untimed pass of the same K steps with every launch bracketed: the per-kernel breakdown
-    _lib.prof_enable(1)
-    for _ in range(args.steps):
-        step()
-    drain()
-    torch.cuda.synchronize()
-    prof_all = _lib.prof_collect()
-    _lib.prof_enable(0)
-    for name, v in prof_all.items():
-        prof.setdefault(name, v)
+    stats_timed = dict(R.PASS_STATS)
+    # second, untimed pass with every launch bracketed: the per-kernel breakdown
+    if not args.no_extras:
+        _lib.prof_enable(1)
+        for _ in range(min(args.steps, 40)):
+            step()
+        drain()
+        torch.cuda.synchronize()
+        prof_all = _lib.prof_collect()
+        _lib.prof_enable(0)
+        for name, v in prof_all.items():
+            prof.setdefault(name, v)
+    else:
+        _lib.prof_enable(0)
     if world > 1:
         te = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
@@ -365,25 +449,46 @@ def main():
         dom_C = int(dom.split("<")[1].rstrip(">")) if "<" in dom and dom.split("<")[1].rstrip(">").isdigit() else 3
         ab = algorithmic_bytes(P, D, npx, dom_C, {3: 48, 9: 54}.get(dom_C, dom_C))
         dom_bytes = ab.get(dom_base)
-        traffic = None
-        hbm_kernels = None
+        # Counter-derived figures are OFFLINE: collected by separate `rocprofv3 --pmc` passes of this same command
+        # (scripts/collect_pmc.py, scripts/collect_sq.py -- a timed run cannot carry counters) and committed under
+        # profiles/ together with the kernel version they were taken on; they are attached only when that version
+        # is the library's (ogs_version()) and the workload is the one profiled.
+        traffic, traffic_src, hbm_kernels, valu = None, None, None, None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        # the committed counter table was collected on the default workload (S1M-1080p, fused pass)
-        if os.path.exists(pmc_file) and args.workload == "S1M-1080p" and fused:
+        sq_file = os.path.join(ROOT, "profiles", "sq_valu.json")
+        libver = int(_lib.lib().ogs_version())
+        profiled = args.workload == "S1M-1080p" and fused and args.views == 8
+        if os.path.exists(pmc_file) and profiled:
             try:
                 pmc = json.load(open(pmc_file))
-                traffic = pmc.get(dom)
-                # measured HBM bytes per launch (PMC) / live launch duration, for every kernel of the step
-                hbm_kernels = {k: {"GBps": pmc[k] / (v["avg_ms"] * 1e-3) / 1e9,
-                                   "frac_of_peak": pmc[k] / (v["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
-                               for k, v in per_kernel.items() if k in pmc and v["avg_ms"] > 0}
+                if int(pmc.get("_ogs_version", -1)) == libver:
+                    traffic = pmc.get(dom)
+                    traffic_src = pmc.get("_source")
+                    # measured HBM bytes per launch (PMC) / live launch duration, for every kernel of the step
+                    hbm_kernels = {k: {"GBps": pmc[k] / (v["avg_ms"] * 1e-3) / 1e9,
+                                       "frac_of_peak": pmc[k] / (v["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+                                   for k, v in per_kernel.items() if k in pmc and v["avg_ms"] > 0}
             except Exception:
                 traffic, hbm_kernels = None, None
+        if os.path.exists(sq_file) and profiled:
+            try:
+                sq = json.load(open(sq_file))
+                if int(sq.get("_ogs_version", -1)) == libver and dom in sq:
+                    n_valu = float(sq[dom]["SQ_INSTS_VALU"])          # VALU wave-instructions per launch
+                    rate = n_valu / (per_kernel[dom]["avg_ms"] * 1e-3) / 1e9
+                    valu = {"bound": "valu", "kernel": dom, "achieved": rate, "peak": VALU_PEAK_GINST, "unit": "G wave-instr/s",
+                            "frac": rate / VALU_PEAK_GINST, "valu_wave_instructions_per_launch": n_valu,
+                            "source": sq.get("_source")}
+            except Exception:
+                valu = None
         roofline = None
         if dom_bytes is not None:
             achieved = dom_bytes / (per_kernel[dom]["avg_ms"] * 1e-3) / 1e9
+            # `bound` names the ruler of this object (HBM bytes, as the bench contract asks); the kernel's actual
+            # limiter is VALU issue -- see `limiter` and the sibling `roofline_valu`
             roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                        "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                        "limiter": "valu-issue (not HBM): see roofline_valu",
                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": per_kernel[dom]["avg_ms"]}
         step_bytes = sum(algorithmic_bytes(P, D, npx, 3, 48)[k] for k in ("fwd", "bwd"))
         if fused:
@@ -398,15 +503,22 @@ def main():
             "config": {"workload": args.workload + (" RGB(SH3) fwd+bwd only" if args.rgb_only else
                                                     (" RGB(SH3)+depth+alpha (all grads) + 6-ch ins_feat (grad to ins_feat) fwd+bwd, " +
                                                      ("ONE fused 9-channel pass" if fused else "two passes (3ch SH + 6ch)"))),
-                       "gaussians": P, "width": W, "height": H, "views_per_step": world,
+                       "gaussians": P, "width": W, "height": H, "views_per_step": world, "views_cycled": V,
                        "parallelism": (f"view-dp{world}: one view per GPU, Gaussians replicated; per step one SUM "
                                        f"all-reduce of the per-Gaussian gradients, "
                                        + ("all-gather of the rank-1 SH-gradient factor, " if compress_sh else "")
                                        + f"MAX all-reduce of radii; exchange {args.exchange}"
                                        + (" (overlaps the next view's render; all exchanges complete in the timed region)"
-                                          if args.exchange == "pipelined" else "")) if world > 1 else "single"},
-            "scene": {"P_visible": p_vis, "D_num_rendered": D, "mean_tile_list": D / gxy},
+                                          if args.exchange == "pipelined" else "")
+                                       + " over RCCL") if dist_on else "single"},
+            "scene": {"P_visible": p_vis, "D_num_rendered": D, "mean_tile_list": D / gxy, "views_cycled": V,
+                      "D_min_max_over_timed_steps": [int(min(info["D_seen"][:args.steps] or [D])),
+                                                     int(max(info["D_seen"][:args.steps] or [D]))]},
+            # how the render phase was sized during the timed steps: sync-free (capacity hint) vs blocking read-back
+            # vs overflow (render phase enqueued twice); the timed value pays for every one of them
+            "render_phase_sizing_timed": {k: stats_timed[k] - stats0[k] for k in stats_timed},
             "roofline": roofline,
+            "roofline_valu": valu,
             "pmc_hbm_rate_per_kernel": hbm_kernels,
             "step_algorithmic_GBps": step_bytes / (ms_per_step * 1e-3) / 1e9,
             "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]["total_ms"])},
@@ -417,9 +529,17 @@ def main():
                 out["kmeans"] = kmeans_bench(device)
             except Exception as e:   # k-means is the second half of the metric, never the headline value
                 out["kmeans"] = {"error": repr(e)}
+        if world == 1 and not args.no_extras:
+            try:
+                log("stage-1 pass (features-only backward)")
+                out["stage1_pass"] = stage1_bench(leaves, all_settings, gF, P, device)
+            except Exception as e:
+                out["stage1_pass"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline (oracle)")
             out["cpu_baseline"] = cpu_baseline(scene_cpu, cam_cpu, W, H, f, args.cpu_tile_stride, args.rgb_only)
+            if "kmeans" in out and "error" not in out["kmeans"]:
+                out["kmeans"]["cpu_baseline"] = kmeans_cpu_baseline()
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -105,7 +105,7 @@ using namespace ogs;
 
 extern "C" {
 
-int ogs_version(void) { return 100; }
+int ogs_version(void) { return 200; }
 
 /* Per-kernel timing with HIP events recorded on the launch stream (bench.py's `roofline` leg).
  * ogs_prof_enable(1) starts a fresh recording; ogs_prof_collect() waits for the recorded events and

@@ -18,13 +18,29 @@ import torch
 import torch.distributed as dist
 
 
+import os as _os
+
+# Rehearsal switch: run every collective even in a ONE-rank group (RCCL executes a 1-rank all-reduce / all-gather /
+# reduce-scatter like any other), so the exact N > 1 code path -- nccl init with device_id, side streams, async
+# work handles, reduce_scatter_tensor -- can be driven on a single-GPU box (tests/test_50_dp_gpu.py, bench.py under
+# `torch.distributed.run --nproc-per-node 1`).  Never set for measurements.
+FORCE_COLLECTIVES = _os.environ.get("OGS_DP_FORCE_COLLECTIVES", "0") == "1"
+
+
+def collectives_on(group=None) -> bool:
+    """True when the exchange must actually call the backend: more than one rank, or the rehearsal switch."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or FORCE_COLLECTIVES
+
+
 def init_from_env(device_type: str = "cuda") -> tuple[int, int, int]:
     """(rank, world_size, local_rank) from torchrun's env; initialises the default group if needed."""
     import os
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or FORCE_COLLECTIVES) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         # "nccl" is RCCL on ROCm.  OGS_DIST_BACKEND=gloo lets several ranks share one GPU for functional
@@ -70,7 +86,7 @@ class GradBucket:
 
     def allreduce_async(self):
         """Start the SUM all-reduce on a side stream (overlaps whatever the caller enqueues next)."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+        if not collectives_on(self.group):
             return
         if self._stream is not None:
             self._stream.wait_stream(torch.cuda.current_stream())
@@ -105,6 +121,7 @@ class ShGradExchange:
         self.group = group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self.on = collectives_on(group)
         self.gathered = torch.zeros(self.world, self.P, 3, dtype=torch.float32, device=device)
         self.local = torch.zeros(self.P, 3, dtype=torch.float32, device=device)     # send buffer (not aliased)
         self._work = None
@@ -112,7 +129,7 @@ class ShGradExchange:
 
     def gather_async(self, dL_drgb: torch.Tensor):
         """Start the all-gather of this rank's [P,3] factor on a side stream."""
-        if self.world == 1:
+        if not self.on:
             self.gathered[0].copy_(dL_drgb)
             return
         local = self.local
@@ -168,7 +185,7 @@ def reduce_max_radii(radii: torch.Tensor, group=None, async_op: bool = False):
     """MAX over views of the screen-space radii (train.py:597).  Returns (tensor, work-or-None)."""
     rmax = radii.to(torch.int32).clone()
     work = None
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if collectives_on(group):
         work = dist.all_reduce(rmax, op=dist.ReduceOp.MAX, group=group, async_op=async_op)
     return rmax, work
 
@@ -183,7 +200,7 @@ def reduce_densification_stats(grad_means2D: torch.Tensor, radii: torch.Tensor, 
     norm = torch.norm(grad_means2D[:, :2], dim=-1) * vis
     cnt = vis.to(torch.float32)
     rmax = radii.to(torch.int32).clone()
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if collectives_on(group):
         packed = torch.stack([norm, cnt])
         dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
         norm, cnt = packed[0], packed[1]
@@ -208,12 +225,20 @@ class ShardedAdam:
         all-gather of the updated slice -> every rank holds the new parameters
 
     Same bytes on the wire as all-reduce + replicated Adam, 1/N of the optimizer time and state.  Per-parameter
-    learning rates as in the reference's param groups (scene/gaussian_model.py:216-224)."""
+    learning rates as in the reference's param groups (scene/gaussian_model.py:216-224).
+
+    torch.optim.Adam semantics are kept per parameter: a parameter whose ``.grad`` is None on EVERY rank is skipped
+    -- value and moments untouched, its own step counter not advanced -- which is what freezes xyz / SH / opacity
+    / scaling / rotation from stage 1 on (train.py:431-436 detaches them, zero_grad(set_to_none=True) at
+    train.py:610); a parameter that first receives a gradient late starts its bias correction at step 1.  The
+    None-mask is agreed across ranks with one tiny MAX all-reduce (a rank whose view missed every Gaussian of a
+    tensor contributes zeros)."""
 
     def __init__(self, named_shapes, lrs, device, group=None, betas=(0.9, 0.999), eps=1e-15):
         self.group = group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self.on = collectives_on(group)
         self.names = [n for n, _ in named_shapes]
         self.shapes = {n: tuple(s) for n, s in named_shapes}
         self.lrs = dict(lrs)
@@ -236,7 +261,7 @@ class ShardedAdam:
         self.my_param = torch.zeros(self.slice, dtype=torch.float32, device=device)
         self.exp_avg = torch.zeros(self.slice, dtype=torch.float32, device=device)
         self.exp_avg_sq = torch.zeros(self.slice, dtype=torch.float32, device=device)
-        self.step_count = 0
+        self.step_counts = {n: 0 for n in self.names}              # per parameter, like torch's state["step"]
 
     def load(self, tensors: dict):
         """initial values (identical on every rank)"""
@@ -248,6 +273,11 @@ class ShardedAdam:
     def step(self):
         from . import _lib
         from ._lib import OgsAdamTensor
+        has = torch.tensor([0.0 if self.params[n].grad is None else 1.0 for n in self.names], dtype=torch.float32,
+                           device=self.flat.device)
+        if self.on:
+            dist.all_reduce(has, op=dist.ReduceOp.MAX, group=self.group)
+        active = {n for n, h in zip(self.names, has.tolist()) if h > 0}
         for n in self.names:
             g = self.params[n].grad
             seg = self.grad[self.offsets[n]:self.offsets[n] + self.params[n].numel()]
@@ -255,8 +285,10 @@ class ShardedAdam:
                 seg.zero_()
             else:
                 seg.copy_(g.reshape(-1))
+        if not active:
+            return
         lo, hi = self.my
-        if self.world > 1:
+        if self.on:
             if dist.get_backend(self.group) == "nccl":
                 dist.reduce_scatter_tensor(self.my_grad, self.grad, op=dist.ReduceOp.SUM, group=self.group)
             else:                                                   # gloo has no reduce-scatter
@@ -265,9 +297,11 @@ class ShardedAdam:
         else:
             self.my_grad.copy_(self.grad[lo:hi])
         self.my_param.copy_(self.flat[lo:hi])
-        self.step_count += 1
         descs = []
-        for n in self.names:                                        # this rank's part of every parameter
+        for n in self.names:                                        # this rank's part of every stepped parameter
+            if n not in active:
+                continue
+            self.step_counts[n] += 1
             a = max(self.offsets[n], lo)
             b = min(self.offsets[n] + self.params[n].numel(), hi)
             if b <= a:
@@ -277,14 +311,14 @@ class ShardedAdam:
             d.grad = self.my_grad.data_ptr() + 4 * (a - lo)
             d.exp_avg = self.exp_avg.data_ptr() + 4 * (a - lo)
             d.exp_avg_sq = self.exp_avg_sq.data_ptr() + 4 * (a - lo)
-            d.numel, d.lr, d.step = b - a, float(self.lrs[n]), self.step_count
+            d.numel, d.lr, d.step = b - a, float(self.lrs[n]), self.step_counts[n]
             descs.append(d)
-        if descs:
-            import ctypes as C
-            arr = (OgsAdamTensor * len(descs))(*descs)
-            _lib.check(_lib.lib().ogs_adam_step(arr, len(descs), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+        for i in range(0, len(descs), 16):                          # OGS_ADAM_MAX_TENSORS per launch
+            chunk = descs[i:i + 16]
+            arr = (OgsAdamTensor * len(chunk))(*chunk)
+            _lib.check(_lib.lib().ogs_adam_step(arr, len(chunk), float(self.betas[0]), float(self.betas[1]), float(self.eps),
                                                 torch.cuda.current_stream().cuda_stream), "ogs_adam_step")
-        if self.world > 1:
+        if self.on:
             dist.all_gather_into_tensor(self.flat, self.my_param, group=self.group)
         else:
             self.flat[lo:hi].copy_(self.my_param)

@@ -5,8 +5,8 @@ Drop-in for ``torch.optim.Adam(l, lr=0.0, eps=1e-15)`` as the reference builds i
 rewrites ``group['lr']`` every iteration, :236-247) and the same per-parameter state dict
 ``{"step", "exp_avg", "exp_avg_sq"}``, so the densification code that reaches into ``optimizer.state``
 (``replace_tensor_to_optimizer`` / ``_prune_optimizer`` / ``cat_tensors_to_optimizer``, :357-430) keeps working.
-``step()`` is ONE HIP launch over all groups (include/ogs_optim.h) instead of one pass per elementwise op and
-group.  No CPU path: parameters must live on the GPU.
+``step()`` is ONE HIP launch over all groups that share betas / eps -- all seven of the reference's -- (include/
+ogs_optim.h; ``last_step_launches`` records the count) instead of one pass per elementwise op and group.  No CPU path: parameters must live on the GPU.
 """
 from __future__ import annotations
 
@@ -35,9 +35,12 @@ class FusedAdam(torch.optim.Optimizer):
         lib = _lib.lib()
         stream = torch.cuda.current_stream().cuda_stream
         keep = []                                   # contiguous gradient copies must outlive the launch call
+        # descriptors of EVERY group, bucketed by (beta1, beta2, eps) -- launch-level constants of ogs_adam_step.  The
+        # reference's seven groups share them (scene/gaussian_model.py:230), so a step is ONE launch.
+        buckets = {}
         for group in self.param_groups:
             beta1, beta2 = group["betas"]
-            descs = []
+            descs = buckets.setdefault((float(beta1), float(beta2), float(group["eps"])), [])
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -66,9 +69,11 @@ class FusedAdam(torch.optim.Optimizer):
                 d.exp_avg, d.exp_avg_sq = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
                 d.numel, d.lr, d.step = p.numel(), float(group["lr"]), int(st["step"].item())
                 descs.append(d)
+        self.last_step_launches = 0
+        for (beta1, beta2, eps), descs in buckets.items():
             for i in range(0, len(descs), MAX_TENSORS):
                 chunk = descs[i:i + MAX_TENSORS]
                 arr = (OgsAdamTensor * len(chunk))(*chunk)
-                check(lib.ogs_adam_step(arr, len(chunk), float(beta1), float(beta2), float(group["eps"]), stream),
-                      "ogs_adam_step")
+                check(lib.ogs_adam_step(arr, len(chunk), beta1, beta2, eps, stream), "ogs_adam_step")
+                self.last_step_launches += 1
         return loss

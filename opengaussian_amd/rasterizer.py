@@ -27,8 +27,33 @@ SUPPORTED_CHANNELS = (3, 6, 9, 12)
 BACKWARD_CHANNELS = (3, 6, 9)          # the gradient record holds C + 7 <= 16 slots
 # diagnostics (scripts/diag_repeat.py): when set to a list, every backward appends its raw gradient-record buffer
 _DEBUG_KEEP_BWD_TMP = None
-# (P, W, H) -> num_rendered of the last pass at that size: capacity hint of the sync-free render phase
+# Capacity hint of the sync-free render phase: (P, W, H) -> num_rendered of the most recent passes at that size.
+# The cameras of a training run take turns, so one pass's count does not predict the next one's: the
+# capacity is 1.25x the MAXIMUM over the last _HINT_WINDOW passes -- after one sweep over the views it covers all of
+# them; a scene that shrinks (pruning) lets the old maxima age out of the window.
 _LAST_NUM_RENDERED: dict = {}
+_HINT_WINDOW = 32
+# how the render phase of every forward was sized: "blocking" (first pass at a size, grouped / debug passes: the
+# reference's 4-byte read-back), "deferred" (sync-free, capacity from the hint), "overflow" (deferred result
+# discarded, render phase redone with exact buffers)
+PASS_STATS = {"blocking": 0, "deferred": 0, "overflow": 0}
+
+
+def _hint_capacity(key):
+    hist = _LAST_NUM_RENDERED.get(key)
+    if not hist:
+        return None
+    return int(max(hist) * 1.25) + 4096
+
+
+def _hint_record(key, D):
+    from collections import deque
+    if len(_LAST_NUM_RENDERED) > 256:      # subset renders come in many sizes: keep the hint table small
+        _LAST_NUM_RENDERED.clear()
+    hist = _LAST_NUM_RENDERED.get(key)
+    if hist is None:
+        hist = _LAST_NUM_RENDERED[key] = deque(maxlen=_HINT_WINDOW)
+    hist.append(int(D))
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -175,8 +200,11 @@ class _RasterizeGaussians(torch.autograd.Function):
             return pl, bt, sr, ql
 
         key = (P, W, H, G)
-        last = _LAST_NUM_RENDERED.get(key)
-        if last is None or rs.debug:
+        # grouped passes: num_rendered follows the group ids of the call (cluster chunk, leaf range), which change
+        # from call to call -> sized by the blocking read-back, like subset passes (their P is new every time)
+        cap = None if (G > 1 or rs.debug) else _hint_capacity(key)
+        if cap is None:
+            PASS_STATS["blocking"] += 1
             # first pass at this size: blocking 4-byte read-back of num_rendered (what the reference does every time)
             n = C.c_int64(0)
             check(lib.ogs_raster_forward_geometry(C.byref(a), stream, C.byref(n)), "ogs_raster_forward_geometry")
@@ -192,17 +220,16 @@ class _RasterizeGaussians(torch.autograd.Function):
             check(lib.ogs_raster_read_num_rendered_async(C.byref(a), stream, pinned.data_ptr()),
                   "ogs_raster_read_num_rendered_async")
             ev.record()
-            cap = int(last * 1.25) + 4096
+            PASS_STATS["deferred"] += 1
             point_list, bin_tmp, sorted_rec, quad_list = alloc_render(cap)
             check(lib.ogs_raster_forward_render_deferred(C.byref(a), cap, stream), "ogs_raster_forward_render_deferred")
             ev.synchronize()
             D = int(pinned.item()) & 0xFFFFFFFF
             if D > cap:
+                PASS_STATS["overflow"] += 1
                 point_list, bin_tmp, sorted_rec, quad_list = alloc_render(D)
                 check(lib.ogs_raster_forward_render(C.byref(a), D, stream), "ogs_raster_forward_render")
-        if len(_LAST_NUM_RENDERED) > 256:      # subset renders come in many sizes: keep the hint table small
-            _LAST_NUM_RENDERED.clear()
-        _LAST_NUM_RENDERED[key] = D
+        _hint_record(key, D)
 
         ctx.num_rendered = D
         ctx.save_for_backward(m3, shs, cols, opac, scl, rot, cov, bg, view, proj, campos, radii, alpha, geom, image,

@@ -319,7 +319,10 @@ def blend(xy, conic, opacity, feats, depth, ranges, point_list, W, H, bg, tiles=
         dy = xy[ids, 1][:, None] - Y[None, :]
         A, B, Cc = conic[ids, 0][:, None], conic[ids, 1][:, None], conic[ids, 2][:, None]
         power = -0.5 * (A * dx * dx + Cc * dy * dy) - B * dx * dy
-        G = torch.exp(power)
+        # exp of a clamped exponent: below -80 the result is a denormal (fp32) that can never reach alpha >= 1/255
+        # (that needs power >= ln(1/255) = -5.5), and denormal arithmetic is 10-50x slower on the host; the
+        # clamp changes no valid contribution and no gradient (clamped entries are masked out by `valid`)
+        G = torch.exp(torch.clamp(power, min=-80.0))
         a_raw = opacity[ids][:, None] * G
         alpha = a_raw + (torch.clamp(a_raw, max=0.99) - a_raw).detach()
         valid = (power <= 0) & (alpha >= 1.0 / 255.0)
@@ -469,16 +472,25 @@ def render_forward(means3D, opacities, viewmatrix, projmatrix, campos, W, H, tan
 
 
 def render_backward_f64(inputs: dict, binning: Binning, W, H, tanfovx, tanfovy, bg,
-                        dL_dcolor, dL_ddepth, dL_dalpha, scale_modifier=1.0, sh_degree=0):
+                        dL_dcolor, dL_ddepth, dL_dalpha, scale_modifier=1.0, sh_degree=0, tiles=None):
     """float64 autograd through preprocess_t + blend with the float32 binning held fixed.
     ``inputs``: dict of numpy arrays with keys means3D, opacities, viewmatrix, projmatrix, campos and
     scales+rotations | cov3D_precomp, shs | colors_precomp.  Returns dict of gradients (numpy f64),
-    including 'means2D' ([P,3], z = 0)."""
+    including 'means2D' ([P,3], z = 0).
+    ``tiles``: optional list of tile ids -- only those tiles are blended (a bounded sample of a full-size
+    scene: the caller passes upstream gradients that are zero outside them, so the result is the exact gradient
+    of that loss)."""
     t64 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
     # Only Gaussians that appear in a tile list receive gradient; restrict the graph to them so
     # culled rows (pvz<=0.2, det==0) cannot inject 0*inf NaNs, then scatter back.
     P_all = np.asarray(inputs["means3D"]).shape[0]
-    used = np.unique(np.asarray(binning.point_list).astype(np.int64))
+    if tiles is None:
+        used = np.unique(np.asarray(binning.point_list).astype(np.int64))
+    else:
+        rg = np.asarray(binning.ranges).astype(np.int64)
+        pl_all = np.asarray(binning.point_list).astype(np.int64)
+        parts = [pl_all[rg[t, 0]:rg[t, 1]] for t in tiles]
+        used = np.unique(np.concatenate(parts)) if parts else np.zeros(0, np.int64)
     remap = np.full(P_all, -1, dtype=np.int64); remap[used] = np.arange(len(used))
     binning = Binning(binning.num_rendered, binning.keys_sorted,
                       remap[np.asarray(binning.point_list).astype(np.int64)], binning.ranges, binning.offsets)
@@ -493,7 +505,8 @@ def render_backward_f64(inputs: dict, binning: Binning, W, H, tanfovx, tanfovy, 
         t64(inputs["projmatrix"]), t64(inputs["campos"]).reshape(3), W, H, float(tanfovx), float(tanfovy),
         leaves.get("scales"), leaves.get("rotations"), leaves.get("cov3D_precomp"), leaves.get("shs"),
         leaves.get("colors_precomp"), scale_modifier, sh_degree)
-    color, dmap, amap, _ = blend(xy, conic, op, rgb, depth, binning.ranges, binning.point_list, W, H, t64(bg))
+    color, dmap, amap, _ = blend(xy, conic, op, rgb, depth, binning.ranges, binning.point_list, W, H, t64(bg),
+                                 tiles=tiles)
     loss = (color * t64(dL_dcolor)).sum() + (dmap * t64(dL_ddepth)).sum() + (amap * t64(dL_dalpha)).sum()
     names = list(leaves)
     grads = torch.autograd.grad(loss, [leaves[n] for n in names], allow_unused=True)

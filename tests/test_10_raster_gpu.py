@@ -264,13 +264,15 @@ def test_deferred_render_phase_and_capacity_overflow(gpu_device):
     inp = helpers.oracle_inputs(sc, cam, use_sh=True)
     key = (2500, W, H, 1)
     R._LAST_NUM_RENDERED.pop(key, None)
+    stats0 = dict(R.PASS_STATS)
     (c0, r0, d0, a0), _ = helpers.hip_forward(inp, cam, (0.1, 0.2, 0.3), 3, gpu_device, requires_grad=True)
-    D = R._LAST_NUM_RENDERED[key]
+    D = R._LAST_NUM_RENDERED[key][-1]
     assert D == c0.grad_fn.num_rendered > 0
     (c1, r1, d1, a1), _ = helpers.hip_forward(inp, cam, (0.1, 0.2, 0.3), 3, gpu_device, requires_grad=True)   # deferred
-    R._LAST_NUM_RENDERED[key] = 7                                                                         # overflow
+    R._LAST_NUM_RENDERED[key].clear(); R._LAST_NUM_RENDERED[key].append(7)                                # overflow
     (c2, r2, d2, a2), _ = helpers.hip_forward(inp, cam, (0.1, 0.2, 0.3), 3, gpu_device, requires_grad=True)
-    assert R._LAST_NUM_RENDERED[key] == D and c2.grad_fn.num_rendered == D
+    assert list(R._LAST_NUM_RENDERED[key]) == [7, D] and c2.grad_fn.num_rendered == D
+    assert {k: R.PASS_STATS[k] - stats0[k] for k in stats0} == {"blocking": 1, "deferred": 2, "overflow": 1}
     for c, r, d, a in ((c1, r1, d1, a1), (c2, r2, d2, a2)):
         assert torch.equal(c, c0) and torch.equal(r, r0) and torch.equal(d, d0) and torch.equal(a, a0)
     k0 = helpers.hip_export_binning(c0)

@@ -56,6 +56,7 @@ def test_fused_adam_matches_torch_adam(gpu_device, P):
             for grp_a, grp_b in zip(ref.param_groups, opt.param_groups):
                 grp_a["lr"] *= 0.5; grp_b["lr"] *= 0.5
         ref.step(); opt.step()
+        assert opt.last_step_launches == 1           # all seven groups (shared betas / eps) in ONE launch
     for n, _, _ in GROUPS:
         assert _max_ulp(gpu[n], cpu[n]) <= PARAM_ULP_BAR, n
         sa, sb = opt.state[gpu[n]], ref.state[cpu[n]]

@@ -182,7 +182,7 @@ def _sharded_adam_rank(rank, world, port, q):
     # single-process truth: FusedAdam on the summed gradients of all ranks
     ref_params = {n: torch.nn.Parameter(init[n].clone()) for n, _ in shapes}
     ref = FusedAdam([{"params": [ref_params[n]], "lr": lrs[n]} for n, _ in shapes], lr=0.0, eps=1e-15)
-    for it in range(4):
+    for it in range(5):
         total = {}
         for r in range(world):
             gr = torch.Generator().manual_seed(100 * it + r)
@@ -191,14 +191,30 @@ def _sharded_adam_rank(rank, world, port, q):
                 total[n] = v if n not in total else total[n] + v
                 if r == rank:
                     opt.params[n].grad = v
+        # torch.optim.Adam semantics per parameter: no gradient on ANY rank -> the parameter is skipped
+        # (value, moments and its own step counter untouched); ins_feat starts late, rotation pauses at step 2
+        skipped = set()
+        if it < 2:
+            skipped.add("ins_feat")
         if it == 2:
-            opt.params["rotation"].grad = None           # no gradient on any rank: the exchange carries zeros
-            total["rotation"] = torch.zeros_like(total["rotation"])
+            skipped.add("rotation")
+        for n in skipped:
+            opt.params[n].grad = None
+        if it == 3 and rank == 1:
+            # None on ONE rank only (its view saw nothing of that tensor): it contributes zeros, the step happens
+            opt.params["opacity"].grad = None
+        if it == 3:
+            gr1 = torch.Generator().manual_seed(100 * it + 1)
+            for n, s in shapes:
+                v = torch.randn(*s, generator=gr1).to(dev)
+                if n == "opacity":
+                    total[n] = total[n] - v
         opt.step()
         for n, _ in shapes:
-            ref_params[n].grad = total[n].clone()
+            ref_params[n].grad = None if n in skipped else total[n].clone()
         ref.step()
     err = {n: float((opt.params[n].detach() - ref_params[n].detach()).abs().max()) for n, _ in shapes}
+    assert opt.step_counts == {"xyz": 5, "f_rest": 5, "opacity": 5, "rotation": 4, "ins_feat": 3}, opt.step_counts
     q.put((rank, err))
     dist.barrier()
     dist.destroy_process_group()
@@ -222,3 +238,109 @@ def test_sharded_adam_two_ranks_match_replicated_adam(gpu_device):
     for rank, err in res:
         for k, e in err.items():
             assert e == 0.0, (rank, k, e)       # two-rank sums are order independent: bit-identical parameters
+
+
+def _nccl_one_rank(port, q):
+    """Child process: backend "nccl" (= RCCL) with ONE rank on cuda:0, every exchange primitive of dp.py forced to
+    call the backend (dp.FORCE_COLLECTIVES), results compared with the no-collective single-process values."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      OGS_DP_FORCE_COLLECTIVES="1")
+    os.environ.pop("OGS_DIST_BACKEND", None)
+    import torch.distributed as dist
+    from opengaussian_amd import dp
+    from opengaussian_amd.optim import FusedAdam
+    from opengaussian_amd.synthetic import make_scene
+    assert dp.FORCE_COLLECTIVES
+    rank, world, local = dp.init_from_env("cuda")
+    assert dist.is_initialized() and dist.get_backend() == "nccl" and world == 1
+    dev = torch.device("cuda", 0)
+    out = {}
+    P, W, H, f = 3000, 128, 80, 100.0
+    scene = make_scene(P, W, H, f, f, seed=3).to(dev)
+    g = torch.Generator().manual_seed(9)
+    gC = torch.randn(3, H, W, generator=g).to(dev)
+    gF = torch.randn(6, H, W, generator=g).to(dev)
+    st, cam = _view_settings(W, H, f, 0, 1, dev)
+    sink = []
+    leaves, radii = _one_view(scene, st, gC, gF, sink)
+    dense, _ = _one_view(scene, st, gC, gF, None)
+    names = ["means3D", "scales", "rotations", "opacities", "ins_feat"]
+    # GradBucket: async all-reduce on the side stream, wait on the compute stream
+    bucket = dp.GradBucket([leaves[n].shape for n in names], dev, average=False)
+    bucket.pack([leaves[n].grad for n in names])
+    bucket.allreduce_async()
+    assert bucket._work is not None                      # the RCCL call was issued
+    red = bucket.wait()
+    out["bucket"] = max(float((a - leaves[n].grad).abs().max()) for a, n in zip(red, names))
+    # ShGradExchange: async all-gather + local rebuild
+    ex = dp.ShGradExchange(P, 16, dev)
+    assert ex.on
+    ex.gather_async(sink[0])
+    assert ex._work is not None
+    dsh = ex.rebuild(scene.means3D, cam.camera_center[None], 3)
+    out["sh"] = float((dsh - dense["shs"].grad).abs().max() / dense["shs"].grad.abs().max())
+    # radii MAX (async) and the blocking statistics reduction
+    rmax, work = dp.reduce_max_radii(radii, async_op=True)
+    assert work is not None
+    work.wait()
+    out["rmax"] = int((rmax != radii).sum())
+    m2g = torch.randn(P, 3, device=dev)
+    norm, cnt, rm2 = dp.reduce_densification_stats(m2g, radii)
+    out["stats"] = float((norm - torch.norm(m2g[:, :2], dim=-1) * (radii > 0)).abs().max())
+    # ShardedAdam: reduce_scatter_tensor -> fused Adam -> all_gather_into_tensor (the nccl branch)
+    shapes = [("xyz", (P, 3)), ("f_rest", (P, 15, 3)), ("ins_feat", (P, 6))]
+    lrs = {"xyz": 1.6e-4, "f_rest": 1.25e-4, "ins_feat": 1e-3}
+    init = {n: torch.randn(*s, generator=g).to(dev) for n, s in shapes}
+    opt = dp.ShardedAdam(shapes, lrs, dev)
+    assert opt.on
+    opt.load(init)
+    refp = {n: torch.nn.Parameter(init[n].clone()) for n, _ in shapes}
+    ref = FusedAdam([{"params": [refp[n]], "lr": lrs[n]} for n, _ in shapes], lr=0.0, eps=1e-15)
+    for it in range(3):
+        for n, s in shapes:
+            v = torch.randn(*s, generator=g).to(dev)
+            opt.params[n].grad = v
+            refp[n].grad = v.clone()
+        opt.step(); ref.step()
+    out["sharded_adam"] = max(float((opt.params[n].detach() - refp[n].detach()).abs().max()) for n, _ in shapes)
+    torch.cuda.synchronize()
+    q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_one_rank_drives_every_exchange_primitive(gpu_device):
+    """RCCL readiness on the one GPU of the test box: a fresh child initialises backend "nccl"
+    with world_size 1 and runs GradBucket.allreduce_async / wait, ShGradExchange.gather_async / rebuild,
+    reduce_max_radii(async_op=True), reduce_densification_stats and ShardedAdam.step()'s reduce_scatter_tensor /
+    all_gather_into_tensor branch through RCCL.  N > 1 over xGMI stays unmeasured until the driver's SCALE run."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_one_rank, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert res["bucket"] == 0.0 and res["rmax"] == 0 and res["stats"] == 0.0 and res["sharded_adam"] == 0.0, res
+    assert res["sh"] < 2e-6, res
+
+
+def test_bench_under_torchrun_one_rank(gpu_device):
+    """bench.py through the driver's launcher (`python -m torch.distributed.run --nproc-per-node 1`) with the
+    collectives forced on: the N > 1 exchange path (double-buffered buckets, side streams, async handles, RCCL)
+    runs end to end on a small workload and prints its one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OGS_DP_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("OGS_DIST_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--workload", "C2-100k-800", "--no-cpu-baseline", "--no-kmeans", "--no-extras"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["value"] > 0 and "RCCL" in out["config"]["parallelism"], out["config"]

@@ -1,10 +1,9 @@
-"""GPU: BASELINE.json configurations at their real sizes.
-
-* C2 (100k Gaussians, 800x800): forward parity against the CPU oracle (images 1e-4, integers bit-exact).
-* S1M-1080p (1M Gaussians, 1920x1080): the oracle would take minutes, so the size-independent properties
-  of the domain are checked instead: sortedness and partition of the binning state, conservation
-  (alpha + T_final), determinism of the forward pass, fused == separate passes, linearity of the backward
-  pass in the upstream gradient, and run-to-run agreement of the float-atomic gradients."""
+"""GPU: size-independent PROPERTIES of the pass at the BASELINE.json metric's size (S1M-1080p: 1M Gaussians,
+1920x1080).  The oracle comparisons at this size live in tests/test_12_baseline_sizes_gpu.py and are collected
+before this file; here: sortedness and partition of the binning state, conservation (alpha + T_final),
+determinism of the forward pass, fused == separate passes, linearity of the backward pass in the upstream
+gradient, and run-to-run REPRODUCIBILITY of the gradients (the per-Gaussian gradient record is accumulated in
+fp64, so the order in which the float atomics arrive no longer shows in the fp32 result)."""
 import math
 
 import numpy as np
@@ -15,34 +14,6 @@ from opengaussian_amd.synthetic import make_camera, make_scene
 from tests import helpers
 
 pytestmark = pytest.mark.gpu
-
-
-def test_c2_forward_parity_vs_oracle(gpu_device):
-    from oracle import raster_oracle as ro
-    torch.set_flush_denormal(True)
-    P, W, H, f = 100_000, 800, 800, 700.0
-    sc = make_scene(P, W, H, f, f, seed=0)
-    cam = make_camera(W, H, f, f)
-    inp = helpers.oracle_inputs(sc, cam, use_sh=True)
-    ref = ro.render_forward(W=W, H=H, tanfovx=W / (2 * f), tanfovy=H / (2 * f), bg=np.zeros(3, np.float32),
-                            sh_degree=3, **inp)
-    (color, radii, depth, alpha), _ = helpers.hip_forward(inp, cam, (0, 0, 0), 3, gpu_device, requires_grad=True)
-    keys, ranges, ncontrib, plist = helpers.hip_export_binning(color)
-    np.testing.assert_array_equal(radii.cpu().numpy(), ref["geom"].radii)
-    np.testing.assert_array_equal(keys, ref["binning"].keys_sorted)
-    np.testing.assert_array_equal(plist, ref["binning"].point_list)
-    np.testing.assert_array_equal(ranges, ref["binning"].ranges)
-    # 1e-4 everywhere except threshold flips: where the device exp and the host exp land on different sides of
-    # alpha >= 1/255 (or T < 1e-4) one contribution of size <= alpha*T*c ~ 4e-3 appears/disappears.  At 1.9M
-    # values a handful of such pixels exist (3 were observed); they are the same pixels n_contrib disagrees on.
-    def close(got, want, tol, flip):
-        diff = np.abs(got - want)
-        assert (diff > tol).mean() < 1e-5, f"{(diff > tol).sum()} values off by more than {tol}"
-        assert diff.max() < flip, f"max diff {diff.max()}"
-    close(color.detach().cpu().numpy(), ref["color"], 1e-4, 4e-3)
-    close(alpha.detach().cpu().numpy(), ref["alpha"], 1e-4, 4e-3)
-    close(depth.detach().cpu().numpy(), ref["depth"], 1e-3, 4e-2)
-    assert (ncontrib != ref["n_contrib"].astype(np.uint32)).mean() < 2e-3
 
 
 @pytest.fixture(scope="module")
@@ -125,5 +96,7 @@ def test_s1m_backward_linearity_and_repeatability(gpu_device, s1m):
         scale = float(gab[k].abs().max()) + 1e-12
         # the backward pass is linear in dL/dcolor
         assert float((ga[k] + gb[k] - gab[k]).abs().max()) / scale < 1e-3, k
-        # float atomics: same inputs agree run to run to rounding
-        assert float((ga[k] - ga2[k]).abs().max()) / scale < 1e-4, k
+        # float atomics land in an fp64 record (order-insensitive to ~1e-16 of the sum of |terms|) that is rounded to
+        # fp32 once: two runs on the same inputs agree to the last few ulp of the LARGEST gradient of the family --
+        # measured bit-identical (profiles/r02_grad_accum_f32_vs_f64.json); the fp32 record gave 1e-5..1e-4 here
+        assert float((ga[k] - ga2[k]).abs().max()) / scale < 1e-6, k
