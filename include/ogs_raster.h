@@ -123,7 +123,11 @@ typedef struct OgsRasterBwdArgs {
     const float* projmatrix;
     const float* campos;
     const int32_t* radii;        /* [P] from forward */
-    const float* out_alpha;      /* [1,H,W] from forward */
+    const float* out_alpha;      /* [1,H,W] from forward: accepted for parity with upstream's argument list, may be NULL.
+                                    Upstream starts the backward's transmittance recursion from 1 - out_alpha; here the
+                                    forward keeps its exact final T per pixel in image_buffer (4 B/pixel) and the
+                                    backward starts from that: 1 - alpha in fp32 is off by up to 6e-4 relative on
+                                    saturated pixels, and that error would scale every gradient of the pixel. */
     const float* dL_dcolor;      /* [C,H,W] */
     const float* dL_ddepth;      /* [1,H,W] or NULL (= zeros) */
     const float* dL_dalpha;      /* [1,H,W] or NULL (= zeros) */

@@ -39,7 +39,7 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 template <int C, int GC, bool DEPTH, typename ACC>
 __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     const uint2* __restrict__ ranges, const float* __restrict__ stream, const uint32_t* __restrict__ quad_list, int W,
-    int H, int gx, int tiles, const float* __restrict__ bg, const float* __restrict__ out_alpha, const uint32_t* __restrict__ n_contrib,
+    int H, int gx, int tiles, const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha_map,
     ACC* __restrict__ grad_rec) {
     constexpr int RS = stream_vec4(C) * 4;
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     const uint32_t lim = n_tile > 0 ? (uint32_t)n_tile - 1u : 0u;
     auto rec_at = [&](uint32_t i) { return tb + (size_t)(min(i, lim) * (uint32_t)RS); };
 
-    const float T_final = inside ? 1.0f - out_alpha[pix] : 0.f;
+    const float T_final = inside ? final_T[pix] : 0.f;      // the forward's own value (ImageState::final_T)
     float T = T_final;
     float g[C];
     float bg_dot = 0.f;
@@ -347,7 +347,7 @@ int launch_c(const OgsRasterBwdArgs& a, const ImageState& is, void* grad_rec_, h
     }
 #define OGS_BWD_LAUNCH(GCV, DEPTHV)                                                                                  \
     OGS_LAUNCH_NAMED(chan_name<C>(kNames), (blend_backward_kernel<C, GCV, DEPTHV, ACC>), dim3(vtiles), dim3(kBlock), 0, s, \
-                     (const uint2*)is.ranges, stream, quads, a.W, a.H, gx, gx * gy, a.bg, a.out_alpha,                  \
+                     (const uint2*)is.ranges, stream, quads, a.W, a.H, gx, gx * gy, a.bg, (const float*)is.final_T,                  \
                      (const uint32_t*)is.n_contrib, a.dL_dcolor, a.dL_ddepth, a.dL_dalpha, grad_rec)
     const bool depth = a.dL_ddepth != nullptr;
     if (a.geom_channels <= 0 || a.geom_channels >= C) {

@@ -161,7 +161,8 @@ template <int C>
 __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ qcount, const float* __restrict__ stream,
     const uint32_t* __restrict__ quad_list, int W, int H, int gx, int tiles, const float* __restrict__ bg, float* __restrict__ out_color,
-    float* __restrict__ out_depth, float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib) {
+    float* __restrict__ out_depth, float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib,
+    float* __restrict__ final_T) {
     constexpr int RS = stream_vec4(C) * 4;      // floats per stream record
     const int tile = blockIdx.x;                // virtual tile (grouped pass): image * tiles + tile in the image
     const int img = tile / tiles, timg = tile - img * tiles;
@@ -260,6 +261,7 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
         out_depth[pix] = (C & 1) ? accp[C / 2].y : accp[C / 2].x;
         out_alpha[pix] = wacc;
         n_contrib[pix] = last;          // index into the QUADRANT stream (+1); see export_n_contrib_kernel
+        final_T[pix] = T;               // the backward starts its T recursion from this, not from 1 - alpha
     }
 }
 
@@ -309,7 +311,7 @@ int launch_c(const OgsRasterFwdArgs& a, const GeomState& gs, const ImageState& i
     OGS_LAUNCH_NAMED(chan_name<C>(kNames), blend_forward_kernel<C>, dim3(vtiles), dim3(kBlock), 0, s,
                      (const uint2*)is.ranges, (const uint32_t*)is.qcount, (const float*)stream_base<C>(a.sorted_rec),
                      (const uint32_t*)quad_base(a.quad_list), a.W, a.H, gx, tiles, a.bg, a.out_color, a.out_depth,
-                     a.out_alpha, is.n_contrib);
+                     a.out_alpha, is.n_contrib, is.final_T);
     OGS_LAUNCH_CHECK(a.debug, s);
     return OGS_OK;
 }

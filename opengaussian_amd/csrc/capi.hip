@@ -254,7 +254,7 @@ int ogs_raster_backward(const OgsRasterBwdArgs* a, void* stream_) {
     if (!a) { set_error("args == NULL"); return OGS_ERR_INVALID_ARG; }
     if (a->C != 3 && a->C != 6 && a->C != 9) { set_error("backward: C=%d unsupported (3, 6, 9)", a->C); return OGS_ERR_UNSUPPORTED; }
     if (a->P == 0) return OGS_OK;
-    if (!a->dL_dcolor || !a->geom_buffer || !a->image_buffer || !a->bwd_tmp || !a->radii || !a->out_alpha || !a->bg ||
+    if (!a->dL_dcolor || !a->geom_buffer || !a->image_buffer || !a->bwd_tmp || !a->radii || !a->bg ||
         !a->means3D || !a->viewmatrix || !a->projmatrix || !a->campos) {
         set_error("backward: NULL required pointer"); return OGS_ERR_INVALID_ARG;
     }

@@ -150,6 +150,10 @@ struct ImageState {     // kept until backward
     uint2* ranges;          // [tiles] range of the tile in the sorted list (reference-exact)
     uint32_t* n_contrib;    // [W*H] last contributor, as 1-based index into the pixel's QUADRANT stream
     uint32_t* qcount;       // [tiles*4] entries kept in each 8x8 quadrant stream
+    float* final_T;         // [W*H] transmittance left after the last contributor, exactly as the forward loop held it.
+                            // The upstream backward re-derives it as 1 - out_alpha (Appendix A.4), which in fp32 loses
+                            // up to eps / T_final = 6e-4 relative on saturated pixels (T_final -> 1e-4) and scales every
+                            // gradient of the pixel by that error; keeping the forward's own value costs 4 B/pixel.
     // G images of a grouped pass are G * tiles "virtual tiles": virtual tile vt = g * tiles + t
     static ImageState carve(void* p, int W, int H, int G = 1) {
         Carver c(p);
@@ -158,6 +162,7 @@ struct ImageState {     // kept until backward
         s.ranges = c.take<uint2>(tiles);
         s.n_contrib = c.take<uint32_t>((size_t)G * W * H);
         s.qcount = c.take<uint32_t>(tiles * 4);
+        s.final_T = c.take<float>((size_t)G * W * H);
         return s;
     }
     static size_t bytes(int W, int H, int G = 1) {
@@ -166,6 +171,7 @@ struct ImageState {     // kept until backward
         c.take<uint2>(tiles);
         c.take<uint32_t>((size_t)G * W * H);
         c.take<uint32_t>(tiles * 4);
+        c.take<float>((size_t)G * W * H);
         return c.off;
     }
 };

@@ -140,36 +140,22 @@ class Quantize_kMeans():
         (kmeans_quantize.py:58-78), so the codebook is frozen between assigns.  Nothing to do."""
         return None
 
-    def update_centers_(self, feat, cluster_mask=None, nn_index=None, avg=False):
-        return cluster_mask.T @ feat
-
-    def rescale(self, feat, scale=None):
-        if scale is None:
-            return feat / (abs(feat).max(dim=0)[0] + 1e-8)
-        return feat / (scale + 1e-8)
-
     def equalize_cluster_size(self, mode="root"):
         """Padded per-cluster index table + lengths (kmeans_quantize.py:89-144), built with one stable sort
         instead of a Python loop over clusters."""
         nn = self.nn_index
         dev = nn.device
         num_clusters = self.num_clusters if mode == "root" else self.num_clusters * self.leaf_num_clusters + 1
+        # Oversized clusters are capped (kmeans_quantize.py:99-117): among the (at most) 100 most populated
+        # clusters, the leading run whose size exceeds max_cnt_th is "excluded" -- its surplus members go to
+        # excl_cluster_ids -- and the table width is the size of the first cluster that is not.
         unq, n_unq = torch.unique(nn, return_counts=True)
-        topk = min(100, len(n_unq))
-        max_cnt_topk, topk_idx = torch.topk(n_unq, topk)
-        self.max_cnt = max_cnt_topk[0]
-        idx = 0
-        self.excl_clusters = []
+        top_cnt, top_idx = torch.topk(n_unq, min(100, n_unq.numel()))        # descending; same tie order as the reference
+        n_excl = int((top_cnt > self.max_cnt_th).sum())
+        self.excl_clusters = sorted(unq[top_idx[:n_excl]])
         self.excl_cluster_ids = []
-        while self.max_cnt > self.max_cnt_th:
-            self.excl_clusters.append(unq[topk_idx[idx]])
-            idx += 1
-            if idx < topk:
-                self.max_cnt = max_cnt_topk[idx]
-            else:
-                break
-        self.n_excl_cls = len(self.excl_clusters)
-        self.excl_clusters = sorted(self.excl_clusters)
+        self.n_excl_cls = n_excl
+        self.max_cnt = top_cnt[min(n_excl, top_cnt.numel() - 1)]
         max_cnt = int(self.max_cnt)
         counts = torch.bincount(nn, minlength=num_clusters)[:num_clusters]
         order = torch.argsort(nn, stable=True)
@@ -233,9 +219,3 @@ class Quantize_kMeans():
             self.update_centers(feat, mode=mode, selected_leaf=selected_leaf)
         centers = self.centers if mode == "root" else self.leaf_centers
         gaussian._ins_feat_q = _GatherSTE.apply(gaussian._ins_feat, centers, self.nn_index, 6)
-
-    def replace_with_centers(self, gaussian):
-        deg = gaussian._features_rest.shape[1]
-        sampled_centers = torch.gather(self.centers, 0, self.nn_index.unsqueeze(-1).repeat(1, self.vec_dim))
-        gaussian._features_rest = gaussian._features_rest - gaussian._features_rest.detach() + \
-            sampled_centers.reshape(-1, deg, 3)

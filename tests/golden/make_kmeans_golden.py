@@ -60,6 +60,23 @@ def run_reference(seed, N, k1, k2):
     q.forward(g, 1, assign=True, mode="root", pos_weight=POS_WEIGHT)
     out = {"root_centers": q.centers.numpy().copy(), "root_ids": q.nn_index.numpy().astype(np.int16),
            "root_q": g._ins_feat_q.detach().numpy().copy()}
+    # the whole Lloyd trajectory, from the reference itself: running it with num_iters = t gives the centres C_t after
+    # t iterations and the ids of the re-assignment with C_t -- exactly the assignment iteration t+1 starts from
+    # (kmeans_quantize.py:173-240).  Lets the GPU test check ONE iteration at a time from the reference's own state,
+    # so that a near-tie flip cannot cascade and every difference is attributable to a row (tests/test_20_kmeans_gpu.py).
+    traj_c, traj_i = [], []
+    for t in range(1, NUM_ITERS + 1):
+        gt = _G()
+        gt._xyz = xyz.clone()
+        gt._ins_feat = ins_feat.clone().requires_grad_(True)
+        qt = kq.Quantize_kMeans(num_clusters=k1, num_leaf_clusters=k2, num_iters=t, dim=9)
+        qt.centers = feat9[init_root].clone()
+        qt.forward(gt, 1, assign=True, mode="root", pos_weight=POS_WEIGHT)
+        traj_c.append(qt.centers.numpy().copy())
+        traj_i.append(qt.nn_index.numpy().astype(np.int16))
+    assert np.array_equal(traj_c[-1], out["root_centers"]) and np.array_equal(traj_i[-1], out["root_ids"])
+    out["root_centers_iter"] = np.stack(traj_c)
+    out["root_ids_iter"] = np.stack(traj_i)
     # non-assign iteration: codebook must stay frozen (update_centers discards its result, :58-78)
     before = q.centers.clone()
     q.forward(g, 2, assign=False, mode="root", pos_weight=POS_WEIGHT)

@@ -104,3 +104,71 @@ def assert_close_modulo_threshold_flips(got, want, tol=1e-4, flip_tol=4e-3, max_
     assert diff.max() < flip_tol, f"max difference {diff.max()}"
     nbad = int((diff > tol).sum())
     assert nbad <= max(max_pixels, 1e-5 * diff.size), f"{nbad} pixels off by more than {tol} (max {diff.max()})"
+
+
+# ---- k-means: per-row attribution of every difference (no fraction-based tolerances) ---------------
+KM_TIE = 1e-5          # ids exact except rows whose best / second-best distance gap < 1e-5
+KM_CENTER_TOL = 1e-4   # north_star tolerance on centres
+
+
+def kmeans_step_attribution(feat, c_prev, c_next_ref, ids_prev_ref, ids_prev_got, c_next_got, what=""):
+    """ONE Lloyd iteration started from the REFERENCE's centres ``c_prev`` (so a near-tie flip cannot cascade):
+
+    * every id that differs from the float64 nearest centre -- in the result under test AND in the reference's own
+      trajectory (its cdist goes through a matmul) -- must sit on a near tie: the distance to the chosen centre
+      exceeds the float64 minimum by < KM_TIE;
+    * the centres under test must equal the float64 mean of THEIR OWN members to 2e-5 (pure arithmetic);
+    * against the reference's next centres ``c_next_ref``: a cluster whose membership is identical on both sides
+      must agree to KM_CENTER_TOL; a cluster that gained / lost near-tie rows may move by at most the sum of
+      those rows' offsets |x - c| / n on top of that -- every centre difference is attributed to named rows.
+    Returns the number of near-tie rows involved (for the log)."""
+    X = np.asarray(feat, np.float64)
+    C = np.asarray(c_prev, np.float64)
+    d = np.sqrt(((X[:, None, :] - C[None, :, :]) ** 2).sum(-1))
+    best = d.argmin(1)
+    dmin = d[np.arange(len(X)), best]
+    for name, ids in (("under test", ids_prev_got), ("reference", ids_prev_ref)):
+        if ids is None:
+            continue
+        ids = np.asarray(ids, np.int64)
+        bad = np.nonzero(ids != best)[0]
+        excess = d[bad, ids[bad]] - dmin[bad]
+        assert (excess < KM_TIE).all(), (f"{what}: {name} ids differ from the f64 nearest centre on rows that are NOT near "
+                                         f"ties: rows {bad[excess >= KM_TIE][:5]} excess {excess.max()}")
+    got = np.asarray(ids_prev_got, np.int64)
+    ref = best if ids_prev_ref is None else np.asarray(ids_prev_ref, np.int64)
+    k = C.shape[0]
+    cg, cr = np.asarray(c_next_got, np.float64), np.asarray(c_next_ref, np.float64)
+    flipped = np.nonzero(got != ref)[0]
+    for j in range(k):
+        members = got == j
+        n = int(members.sum())
+        if n:
+            mean = X[members].mean(0)
+            assert np.abs(cg[j] - mean).max() < 2e-5, f"{what}: centre {j} is not the mean of its {n} members"
+        else:
+            assert np.abs(cg[j]).max() < 1e-5, f"{what}: empty cluster {j} must collapse to ~0 (kmeans_quantize.py:209)"
+        touching = flipped[(got[flipped] == j) | (ref[flipped] == j)]
+        allowed = KM_CENTER_TOL + sum(np.abs(X[r] - cr[j]).max() for r in touching) / max(min(n, int((ref == j).sum())), 1)
+        assert np.abs(cg[j] - cr[j]).max() <= allowed, (f"{what}: centre {j} off by {np.abs(cg[j] - cr[j]).max()} with "
+                                                          f"{len(touching)} near-tie rows touching it (allowed {allowed})")
+    return len(flipped)
+
+
+def kmeans_final_ids_attribution(feat, c_ref, ids_ref, c_got, ids_got, what=""):
+    """End of a multi-iteration run: centres may differ by delta (itself bounded by the caller), which shifts every
+    distance by <= delta -- so an id may differ from the reference's only where the two candidate centres are within
+    KM_TIE + 2 * delta of each other for that row (float64, reference centres)."""
+    X = np.asarray(feat, np.float64)
+    C = np.asarray(c_ref, np.float64)
+    delta = float(np.abs(np.asarray(c_got, np.float64) - C).max())
+    got, ref = np.asarray(ids_got, np.int64), np.asarray(ids_ref, np.int64)
+    bad = np.nonzero(got != ref)[0]
+    if len(bad) == 0:
+        return 0
+    da = np.sqrt(((X[bad] - C[got[bad]]) ** 2).sum(-1))
+    db = np.sqrt(((X[bad] - C[ref[bad]]) ** 2).sum(-1))
+    gap = np.abs(da - db)
+    assert (gap < KM_TIE + 2 * delta).all(), (f"{what}: ids differ on rows whose candidate centres are NOT within "
+                                              f"{KM_TIE} + 2*{delta:.2e}: rows {bad[gap >= KM_TIE + 2 * delta][:5]}, gap {gap.max()}")
+    return len(bad)

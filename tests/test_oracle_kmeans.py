@@ -69,6 +69,27 @@ def test_oracle_matches_reference_golden(seed, N, k1, k2):
     np.testing.assert_array_equal(np.bincount(leaf_ref, minlength=k1 * k2 + 1), key("cluster_len_leaf"))
 
 
+@pytest.mark.parametrize("seed,N,k1,k2", _cases())
+def test_oracle_follows_reference_trajectory_step_by_step(seed, N, k1, k2):
+    """Every Lloyd iteration of the reference's own trajectory (root_centers_iter / root_ids_iter, produced by
+    running the reference with num_iters = 1..5) re-done by the oracle FROM THE REFERENCE'S centres: each id and
+    centre difference is attributed to a near-tie row (tests/helpers.py::kmeans_step_attribution)."""
+    from tests import helpers
+    g = np.load(GOLD)
+    key = lambda name: g[f"s{seed}_n{N}_{name}"]
+    ins_feat, xyz, init_root, _, _ = case_inputs(seed, N, k1, k2)
+    feat9 = torch.cat((ins_feat, xyz * POS_WEIGHT), dim=1).numpy()
+    traj_c, traj_i = key("root_centers_iter"), key("root_ids_iter").astype(np.int64)
+    c_prev = feat9[init_root.numpy()].copy()
+    for t in range(NUM_ITERS):
+        ids_pre = ko._argmin_sqdist(feat9, c_prev)
+        c_next, _ = ko.lloyd(feat9, c_prev, iters=1)
+        helpers.kmeans_step_attribution(feat9, c_prev, traj_c[t], traj_i[t - 1] if t > 0 else None, ids_pre, c_next,
+                                        what=f"iteration {t + 1}")
+        c_prev = traj_c[t]
+    assert np.array_equal(traj_c[-1], key("root_centers"))
+
+
 def test_empty_cluster_collapses_to_zero():
     """kmeans_quantize.py:209,213-214: an empty cluster's centre becomes ~0 and is never re-seeded."""
     feat = np.random.default_rng(0).random((500, 6)).astype(np.float32)
