@@ -189,6 +189,18 @@ int ogs_raster_forward_render(const OgsRasterFwdArgs* args, int64_t num_rendered
 int ogs_raster_read_num_rendered_async(const OgsRasterFwdArgs* args, void* stream, uint32_t* host_pinned);
 int ogs_raster_forward_render_deferred(const OgsRasterFwdArgs* args, int64_t capacity, void* stream);
 
+/* Tiny pass: the whole forward in TWO launches for P <= ogs_raster_tiny_max_points() Gaussians (ungrouped) -- the
+ * single-Gaussian footprint renders of the SAM refiner (utils/sam_refinement_utils.py:330-403: one P = 1 call per
+ * Gaussian and camera, thousands of times) and other very small subset renders, where the ~25 launches of the
+ * streaming path are pure launch latency.  One workgroup preprocesses and depth-sorts every Gaussian; one workgroup
+ * per tile then collects the Gaussians whose tile rect covers it (the reference's tile list, in its order) and blends
+ * them.  Same images, radii, depth and alpha as the two-phase path, bit for bit.  Needs out_*, radii, geom_buffer
+ * and geom_tmp; image_buffer / point_list / binning_tmp / sorted_rec / quad_list are not used and nothing is kept
+ * for a backward pass (a caller that needs gradients re-renders through the two-phase path).  Asynchronous, no
+ * read-back. */
+size_t ogs_raster_tiny_max_points(void);
+int ogs_raster_forward_tiny(const OgsRasterFwdArgs* args, void* stream);
+
 /* Backward.  Asynchronous on `stream`. */
 int ogs_raster_backward(const OgsRasterBwdArgs* args, void* stream);
 

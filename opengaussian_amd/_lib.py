@@ -50,6 +50,16 @@ class OgsAdamTensor(C.Structure):
                 ("lr", C.c_double), ("step", C.c_int64)]
 
 
+class OgsRowTensor(C.Structure):
+    _fields_ = [("src", _vp), ("dst", _vp), ("width", C.c_int32), ("zero_new", C.c_int32)]
+
+
+class OgsDensifyArgs(C.Structure):
+    _fields_ = [("N", C.c_int32), ("grad_accum", _vp), ("denom", _vp), ("scaling", _vp), ("opacity", _vp),
+                ("max_grad", C.c_float), ("min_opacity", C.c_float), ("extent", C.c_float), ("percent_dense", C.c_float),
+                ("prune_world_size", C.c_int32)]
+
+
 # name -> (restype, argtypes); also the list the symbol-export test checks against the headers
 SIGNATURES = {
     "ogs_version": (C.c_int, []),
@@ -67,6 +77,8 @@ SIGNATURES = {
     "ogs_raster_read_num_rendered_async": (C.c_int, [C.POINTER(OgsRasterFwdArgs), _vp, _vp]),
     "ogs_raster_forward_render_deferred": (C.c_int, [C.POINTER(OgsRasterFwdArgs), C.c_int64, _vp]),
     "ogs_raster_backward": (C.c_int, [C.POINTER(OgsRasterBwdArgs), _vp]),
+    "ogs_raster_tiny_max_points": (C.c_size_t, []),
+    "ogs_raster_forward_tiny": (C.c_int, [C.POINTER(OgsRasterFwdArgs), _vp]),
     "ogs_mark_visible": (C.c_int, [C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "ogs_sh_grad_from_views": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "ogs_raster_export_binning": (C.c_int, [C.POINTER(OgsRasterFwdArgs), C.c_int64, _vp, _vp, _vp, _vp]),
@@ -83,6 +95,12 @@ SIGNATURES = {
     "ogs_mask_cohesion": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int64, _vp, _vp]),
     "ogs_mask_cohesion_backward": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int64, _vp, _vp, _vp]),
     "ogs_adam_step": (C.c_int, [C.POINTER(OgsAdamTensor), C.c_int32, C.c_double, C.c_double, C.c_double, _vp]),
+    "ogs_rows_gather": (C.c_int, [C.POINTER(OgsRowTensor), C.c_int32, _vp, _vp, C.c_int64, _vp]),
+    "ogs_densify_tmp_bytes": (C.c_size_t, [C.c_int32]),
+    "ogs_densify_plan": (C.c_int, [C.POINTER(OgsDensifyArgs), _vp, C.POINTER(C.c_uint32), _vp]),
+    "ogs_densify_map": (C.c_int, [C.c_int32, _vp, _vp, _vp, _vp, _vp]),
+    "ogs_densify_split_children": (C.c_int, [C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ogs_densify_stats": (C.c_int, [C.c_int32, _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ogs_kmeans_accumulate": (C.c_int, [_vp, C.c_int64, C.c_int32, _vp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
     "ogs_kmeans_update": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp]),
     "ogs_kmeans_gather": (C.c_int, [_vp, _vp, C.c_int64, C.c_int32, C.c_int32, _vp, _vp]),

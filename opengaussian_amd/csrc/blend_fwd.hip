@@ -291,6 +291,128 @@ __global__ __launch_bounds__(kBlock) void export_n_contrib_kernel(const uint2* _
     out[(size_t)py * W + px] = res;
 }
 
+// Tiny pass (P <= kTinyMaxP, see preprocess_fwd.hip::tiny_geometry_kernel): no duplicate / sort / ranges / pack.  One
+// workgroup per tile walks the P depth-sorted Gaussians, keeps those whose tile rect (A.1 step 8) covers the tile --
+// exactly the reference's tile list, in its order -- stages their blend records in LDS and blends them with the
+// same arithmetic as blend_forward_kernel (same record fields, same FMA shapes), so the images equal the streaming
+// path's bit for bit.  2 launches per pass instead of ~25; nothing is kept for a backward pass (the facade
+// re-renders through the streaming path if backward() is ever called on a tiny pass).
+template <int C>
+__global__ __launch_bounds__(kBlock) void tiny_blend_kernel(int P, const uint32_t* __restrict__ order,
+                                                            const float4* __restrict__ rec, int W, int H, int gx,
+                                                            const float* __restrict__ bg, float* __restrict__ out_color,
+                                                            float* __restrict__ out_depth, float* __restrict__ out_alpha) {
+    constexpr int NV = rec_vec4(C);
+    constexpr int RS = 8 + (C + 1 + 3) / 4 * 4;                 // floats per staged record (geometry 8, features + depth)
+    static_assert(kTinyMaxP == kBlock, "one staging round");
+    __shared__ float s_rec[kTinyMaxP * RS];
+    __shared__ uint32_t s_wave_cnt[kBlock / kWave];
+    const int tile = blockIdx.x;
+    const int tx = tile % gx, ty = tile / gx;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gy = (H + kTile - 1) / kTile;
+
+    // ---- tile list: sorted position tid -> does its rect cover this tile? ----------------------------------------
+    bool keep = false;
+    float4 a = make_float4(0, 0, 0, 0), b = a;
+    uint32_t gid = 0;
+    if (tid < P) {
+        gid = order[tid];
+        const float4* src = rec + (size_t)gid * NV;
+        a = src[0]; b = src[1];
+        const int radius = __float_as_int(a.w);
+        if (radius > 0) {
+            const float rf = (float)radius;
+            auto tr = [](float v) -> int {
+                if (!(fabsf(v) < 3.0e38f)) v = 0.f;
+                v = fminf(fmaxf(v, -2.0e9f), 2.0e9f);
+                return (int)v;
+            };
+            // same expressions as preprocess / duplicate (division by 16 and the +15 are exact in fp32)
+            const int rminx = min(gx, max(0, tr((a.x - rf) / (float)kTile)));
+            const int rminy = min(gy, max(0, tr((a.y - rf) / (float)kTile)));
+            const int rmaxx = min(gx, max(0, tr((a.x + rf + (float)kTile - 1.0f) / (float)kTile)));
+            const int rmaxy = min(gy, max(0, tr((a.y + rf + (float)kTile - 1.0f) / (float)kTile)));
+            keep = tx >= rminx && tx < rmaxx && ty >= rminy && ty < rmaxy;
+        }
+    }
+    const uint64_t bal = __ballot(keep);
+    if (lane == 0) s_wave_cnt[wave] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    uint32_t before = 0, n = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / kWave; ++w) {
+        const uint32_t c = s_wave_cnt[w];
+        if (w < wave) before += c;
+        n += c;
+    }
+    if (keep) {
+        const uint32_t pos = before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        float* dst = s_rec + pos * RS;
+        dst[0] = a.x; dst[1] = a.y; dst[2] = -0.5f * b.x; dst[3] = -b.y; dst[4] = -0.5f * b.z;
+        dst[5] = 0.5f * (__logf(255.0f * b.w) + kThrMargin);
+        dst[6] = b.w; dst[7] = __uint_as_float(gid);
+        const float4* src = rec + (size_t)gid * NV;
+        float f[(NV - 2) * 4 + 4];
+#pragma unroll
+        for (int v = 0; v < NV - 2; ++v) {
+            const float4 t = src[2 + v];
+            f[4 * v] = t.x; f[4 * v + 1] = t.y; f[4 * v + 2] = t.z; f[4 * v + 3] = t.w;
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) dst[8 + c] = f[c];
+        dst[8 + C] = a.z;
+    }
+    __syncthreads();
+
+    // ---- blend (A.3), one pixel per thread, same arithmetic as blend_forward_kernel::consume ------------------
+    const int px = tx * kTile + (wave & 1) * 8 + (lane & 7);
+    const int py = ty * kTile + (wave >> 1) * 8 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const float fx = (float)px, fy = (float)py;
+    float T = 1.0f, wacc = 0.f;
+    float acc[C + 1];
+#pragma unroll
+    for (int c = 0; c <= C; ++c) acc[c] = 0.f;
+    bool done = !inside;
+    for (uint32_t j = 0; j < n; ++j) {
+        if (__ballot(!done) == 0ull) break;
+        const float* r = s_rec + j * RS;                          // wave-uniform LDS address: broadcast reads
+        const float dx = r[0] - fx, dy = r[1] - fy;
+        const float power = r[2] * dx * dx + r[4] * dy * dy + r[3] * dx * dy;
+        const bool cand = !done && fabsf(power + r[5]) <= r[5];
+        if (cand) {
+            float alpha = fminf(0.99f, r[6] * __expf(power));
+            alpha = alpha >= kAlphaMin ? alpha : 0.f;
+            const float test_T = T * (1.0f - alpha);
+            const bool stop = test_T < 0.0001f;
+            const float w = stop ? 0.f : alpha * T;
+#pragma unroll
+            for (int c = 0; c <= C; ++c) acc[c] = fmaf(r[8 + c], w, acc[c]);
+            wacc += w;
+            T = stop ? T : test_T;
+            done = stop;
+        }
+    }
+    if (inside) {
+        const size_t plane = (size_t)W * H;
+        const size_t pix = (size_t)py * W + px;
+#pragma unroll
+        for (int c = 0; c < C; ++c) out_color[c * plane + pix] = acc[c] + T * bg[c];
+        out_depth[pix] = acc[C];
+        out_alpha[pix] = wacc;
+    }
+}
+
+template <int C>
+int tiny_c(const OgsRasterFwdArgs& a, const GeomState& gs, const uint32_t* order, hipStream_t s) {
+    const int gx = (a.W + kTile - 1) / kTile, gy = (a.H + kTile - 1) / kTile;
+    OGS_LAUNCH(tiny_blend_kernel<C>, dim3((unsigned)(gx * gy)), dim3(kBlock), 0, s, a.P, order, (const float4*)gs.rec, a.W, a.H,
+               gx, a.bg, a.out_color, a.out_depth, a.out_alpha);
+    OGS_LAUNCH_CHECK(a.debug, s);
+    return OGS_OK;
+}
+
 template <int C>
 int launch_c(const OgsRasterFwdArgs& a, const GeomState& gs, const ImageState& is, int64_t D, hipStream_t s) {
     const int gx = (a.W + kTile - 1) / kTile, gy = (a.H + kTile - 1) / kTile;
@@ -335,6 +457,16 @@ int launch_blend_forward(const OgsRasterFwdArgs& a, const GeomState& gs, const I
         case 6: return launch_c<6>(a, gs, is, D, s);
         case 9: return launch_c<9>(a, gs, is, D, s);
         case 12: return launch_c<12>(a, gs, is, D, s);
+        default: set_error("unsupported channel count C=%d", a.C); return OGS_ERR_UNSUPPORTED;
+    }
+}
+
+int launch_tiny_blend(const OgsRasterFwdArgs& a, const GeomState& gs, const uint32_t* order, hipStream_t s) {
+    switch (a.C) {
+        case 3: return tiny_c<3>(a, gs, order, s);
+        case 6: return tiny_c<6>(a, gs, order, s);
+        case 9: return tiny_c<9>(a, gs, order, s);
+        case 12: return tiny_c<12>(a, gs, order, s);
         default: set_error("unsupported channel count C=%d", a.C); return OGS_ERR_UNSUPPORTED;
     }
 }

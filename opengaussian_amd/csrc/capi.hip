@@ -88,8 +88,9 @@ static int validate_fwd(const OgsRasterFwdArgs* a) {
             return OGS_ERR_INVALID_ARG;
         }
     }
-    if (!a->bg || !a->viewmatrix || !a->projmatrix || !a->campos || !a->out_color || !a->out_depth || !a->out_alpha ||
-        !a->image_buffer) { set_error("NULL required pointer"); return OGS_ERR_INVALID_ARG; }
+    if (!a->bg || !a->viewmatrix || !a->projmatrix || !a->campos || !a->out_color || !a->out_depth || !a->out_alpha) {
+        set_error("NULL required pointer"); return OGS_ERR_INVALID_ARG;
+    }
     if (a->P > 0 && (!a->means3D || !a->opacities || !a->radii || !a->geom_buffer || !a->geom_tmp)) {
         set_error("NULL required per-Gaussian pointer"); return OGS_ERR_INVALID_ARG;
     }
@@ -204,6 +205,7 @@ int ogs_raster_read_num_rendered_async(const OgsRasterFwdArgs* a, void* stream_,
 static int render_impl(const OgsRasterFwdArgs* a, int64_t D, bool deferred, hipStream_t s) {
     int rc = validate_fwd(a);
     if (rc != OGS_OK) return rc;
+    if (!a->image_buffer) { set_error("image_buffer == NULL"); return OGS_ERR_INVALID_ARG; }
     const int G = num_groups_of(a->num_groups);
     const ImageState is = ImageState::carve(a->image_buffer, a->W, a->H, G);
     const int gx = (a->W + kTile - 1) / kTile, gy = (a->H + kTile - 1) / kTile;
@@ -248,6 +250,21 @@ int ogs_raster_forward_render(const OgsRasterFwdArgs* a, int64_t D, void* stream
 int ogs_raster_forward_render_deferred(const OgsRasterFwdArgs* a, int64_t capacity, void* stream_) {
     if (capacity <= 0) { set_error("forward_render_deferred: capacity must be > 0"); return OGS_ERR_INVALID_ARG; }
     return render_impl(a, capacity, true, static_cast<hipStream_t>(stream_));
+}
+
+size_t ogs_raster_tiny_max_points(void) { return (size_t)kTinyMaxP; }
+
+int ogs_raster_forward_tiny(const OgsRasterFwdArgs* a, void* stream_) {
+    int rc = validate_fwd(a);
+    if (rc != OGS_OK) return rc;
+    if (a->P <= 0 || a->P > kTinyMaxP) { set_error("forward_tiny: P=%d outside [1, %d]", a->P, kTinyMaxP); return OGS_ERR_INVALID_ARG; }
+    if (a->num_groups > 1) { set_error("forward_tiny: grouped passes use the streaming path"); return OGS_ERR_UNSUPPORTED; }
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    const GeomState gs = GeomState::carve(a->geom_buffer, a->P, a->C);
+    uint32_t* order = static_cast<uint32_t*>(a->geom_tmp);        // [P] depth order; geom_tmp >= ogs_raster_geom_tmp_bytes(P)
+    rc = launch_tiny_geometry(*a, gs, order, s);
+    if (rc != OGS_OK) return rc;
+    return launch_tiny_blend(*a, gs, order, s);
 }
 
 int ogs_raster_backward(const OgsRasterBwdArgs* a, void* stream_) {

@@ -90,20 +90,18 @@ __device__ __forceinline__ void sh_to_rgb(int idx, int deg, int M, const float* 
     }
 }
 
+// One Gaussian of A.1 (shared by the streaming kernel and the single-workgroup kernel of the tiny pass).
+// Returns the depth-sort key: positive float bits are order preserving; culled Gaussians sort last.
 template <int C>
-__global__ __launch_bounds__(kBlock) void preprocess_kernel(
-    int P, int W, int H, int sh_degree, int sh_coeffs, float tanfovx, float tanfovy, float focal_x, float focal_y,
+__device__ __forceinline__ uint32_t preprocess_one(
+    int idx, int W, int H, int sh_degree, int sh_coeffs, float tanfovx, float tanfovy, float focal_x, float focal_y,
     float scale_modifier, const float* __restrict__ means3D, const float* __restrict__ colors_precomp,
     const float* __restrict__ shs, const float* __restrict__ opacities, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix,
     const float* __restrict__ projmatrix, const float* __restrict__ campos, float4* __restrict__ rec,
     uint32_t* __restrict__ clamped_out, int32_t* __restrict__ radii, uint32_t* __restrict__ tiles_touched,
-    uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ order, const int32_t* __restrict__ group_ids,
-    int num_groups) {
+    const int32_t* __restrict__ group_ids, int num_groups) {
     constexpr int NV = rec_vec4(C);
-    const int idx = blockIdx.x * kBlock + threadIdx.x;
-    if (idx >= P) return;
-
     // camera matrices: wave-uniform addresses -> scalar loads
     float V[16], M[16];
 #pragma unroll
@@ -235,10 +233,57 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(
     for (int v = 0; v < NV - 2; ++v) r[2 + v] = make_float4(feat[4 * v], feat[4 * v + 1], feat[4 * v + 2], feat[4 * v + 3]);
     clamped_out[idx] = clamped;
     radii[idx] = radius;
-    tiles_touched[idx] = touched;
-    // depth-sort key: positive float bits are order preserving; culled Gaussians sort last
-    depth_keys[idx] = ok ? __float_as_uint(depth) : 0xFFFFFFFFu;
+    if (tiles_touched) tiles_touched[idx] = touched;
+    return ok ? __float_as_uint(depth) : 0xFFFFFFFFu;
+}
+
+template <int C>
+__global__ __launch_bounds__(kBlock) void preprocess_kernel(
+    int P, int W, int H, int sh_degree, int sh_coeffs, float tanfovx, float tanfovy, float focal_x, float focal_y,
+    float scale_modifier, const float* __restrict__ means3D, const float* __restrict__ colors_precomp,
+    const float* __restrict__ shs, const float* __restrict__ opacities, const float* __restrict__ scales,
+    const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix,
+    const float* __restrict__ projmatrix, const float* __restrict__ campos, float4* __restrict__ rec,
+    uint32_t* __restrict__ clamped_out, int32_t* __restrict__ radii, uint32_t* __restrict__ tiles_touched,
+    uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ order, const int32_t* __restrict__ group_ids,
+    int num_groups) {
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= P) return;
+    depth_keys[idx] = preprocess_one<C>(idx, W, H, sh_degree, sh_coeffs, tanfovx, tanfovy, focal_x, focal_y, scale_modifier,
+                                        means3D, colors_precomp, shs, opacities, scales, rotations, cov3D_precomp, viewmatrix,
+                                        projmatrix, campos, rec, clamped_out, radii, tiles_touched, group_ids, num_groups);
     order[idx] = (uint32_t)idx;
+}
+
+// Tiny pass (P <= kTinyMaxP; the SAM refiner's single-Gaussian footprint queries, utils/sam_refinement_utils.py:330-403,
+// and the small subset renders of stages 2.2 / 3): ONE workgroup preprocesses every Gaussian and depth-sorts them in
+// LDS (rank sort on (depth bits, index): the reference's tile-list order restricted to any tile), so the whole
+// geometry phase -- preprocess, 4 radix passes, scan, read-back in the streaming path: ~15 launches -- is one launch.
+template <int C>
+__global__ __launch_bounds__(kTinyMaxP) void tiny_geometry_kernel(
+    int P, int W, int H, int sh_degree, int sh_coeffs, float tanfovx, float tanfovy, float focal_x, float focal_y,
+    float scale_modifier, const float* __restrict__ means3D, const float* __restrict__ colors_precomp,
+    const float* __restrict__ shs, const float* __restrict__ opacities, const float* __restrict__ scales,
+    const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix,
+    const float* __restrict__ projmatrix, const float* __restrict__ campos, float4* __restrict__ rec,
+    uint32_t* __restrict__ clamped_out, int32_t* __restrict__ radii, uint32_t* __restrict__ order) {
+    __shared__ uint32_t s_key[kTinyMaxP];
+    const int idx = threadIdx.x;
+    uint32_t key = 0xFFFFFFFFu;
+    if (idx < P)
+        key = preprocess_one<C>(idx, W, H, sh_degree, sh_coeffs, tanfovx, tanfovy, focal_x, focal_y, scale_modifier, means3D,
+                                colors_precomp, shs, opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
+                                campos, rec, clamped_out, radii, nullptr, nullptr, 0);
+    s_key[idx] = key;
+    __syncthreads();
+    if (idx < P) {
+        int rank = 0;
+        for (int j = 0; j < P; ++j) {
+            const uint32_t kj = s_key[j];
+            rank += (kj < key || (kj == key && j < idx)) ? 1 : 0;
+        }
+        order[rank] = (uint32_t)idx;
+    }
 }
 
 // Emit one (tile id, Gaussian id) pair per touched tile, Gaussians visited in DEPTH order so that a
@@ -364,7 +409,28 @@ int launch_preprocess_c(const OgsRasterFwdArgs& a, const GeomState& gs, const Ge
     return OGS_OK;
 }
 
+template <int C>
+int launch_tiny_geometry_c(const OgsRasterFwdArgs& a, const GeomState& gs, uint32_t* order, hipStream_t s) {
+    const float focal_x = (float)a.W / (2.0f * a.tanfovx);
+    const float focal_y = (float)a.H / (2.0f * a.tanfovy);
+    OGS_LAUNCH(tiny_geometry_kernel<C>, dim3(1), dim3(kTinyMaxP), 0, s, a.P, a.W, a.H, a.sh_degree, a.sh_coeffs, a.tanfovx,
+               a.tanfovy, focal_x, focal_y, a.scale_modifier, a.means3D, a.colors_precomp, a.shs, a.opacities, a.scales,
+               a.rotations, a.cov3D_precomp, a.viewmatrix, a.projmatrix, a.campos, gs.rec, gs.clamped, a.radii, order);
+    OGS_LAUNCH_CHECK(a.debug, s);
+    return OGS_OK;
+}
+
 }  // namespace
+
+int launch_tiny_geometry(const OgsRasterFwdArgs& a, const GeomState& gs, uint32_t* order, hipStream_t s) {
+    switch (a.C) {
+        case 3: return launch_tiny_geometry_c<3>(a, gs, order, s);
+        case 6: return launch_tiny_geometry_c<6>(a, gs, order, s);
+        case 9: return launch_tiny_geometry_c<9>(a, gs, order, s);
+        case 12: return launch_tiny_geometry_c<12>(a, gs, order, s);
+        default: set_error("unsupported channel count C=%d (3, 6, 9 or 12)", a.C); return OGS_ERR_UNSUPPORTED;
+    }
+}
 
 int launch_preprocess(const OgsRasterFwdArgs& a, const GeomState& gs, const GeomTmp& gt, hipStream_t s) {
     switch (a.C) {

@@ -25,6 +25,10 @@ from ._lib import OgsRasterBwdArgs, OgsRasterFwdArgs, check, ptr
 
 SUPPORTED_CHANNELS = (3, 6, 9, 12)
 BACKWARD_CHANNELS = (3, 6, 9)          # the gradient record holds C + 7 <= 16 slots
+# Passes with at most this many Gaussians (ungrouped) take the two-launch tiny path (ogs_raster_forward_tiny): the
+# SAM refiner's P = 1 footprint renders and other very small subsets.  0 disables it (the parity tests that export the
+# binning state of small scenes do).  Never larger than ogs_raster_tiny_max_points().
+TINY_MAX_P = 256
 # diagnostics (scripts/diag_repeat.py): when set to a list, every backward appends its raw gradient-record buffer
 _DEBUG_KEEP_BWD_TMP = None
 # Capacity hint of the sync-free render phase: (P, W, H) -> num_rendered of the most recent passes at that size.
@@ -36,7 +40,7 @@ _HINT_WINDOW = 32
 # how the render phase of every forward was sized: "blocking" (first pass at a size, grouped / debug passes: the
 # reference's 4-byte read-back), "deferred" (sync-free, capacity from the hint), "overflow" (deferred result
 # discarded, render phase redone with exact buffers)
-PASS_STATS = {"blocking": 0, "deferred": 0, "overflow": 0}
+PASS_STATS = {"blocking": 0, "deferred": 0, "overflow": 0, "tiny": 0, "tiny_rerendered_for_backward": 0}
 
 
 def _hint_capacity(key):
@@ -98,6 +102,74 @@ def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 def _require_gpu(t: torch.Tensor, name: str):
     if not t.is_cuda:
         raise RuntimeError(f"{name} must live on the GPU (got {t.device}); the MI355X rasterizer has no CPU path")
+
+
+def _fwd_args(rs, P, Cn, m3, shs, cols, opac, scl, rot, cov, bg, view, proj, campos, color, depth, alpha, radii, group_ids, G):
+    a = OgsRasterFwdArgs()
+    a.P, a.W, a.H, a.C = P, int(rs.image_width), int(rs.image_height), Cn
+    a.sh_degree = int(rs.sh_degree)
+    a.sh_coeffs = 0 if shs is None else int(shs.shape[1])
+    a.tanfovx, a.tanfovy, a.scale_modifier = float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier)
+    a.prefiltered, a.debug = int(bool(rs.prefiltered)), int(bool(rs.debug))
+    a.bg, a.means3D, a.colors_precomp, a.shs, a.opacities = ptr(bg), ptr(m3), ptr(cols), ptr(shs), ptr(opac)
+    a.scales, a.rotations, a.cov3D_precomp = ptr(scl), ptr(rot), ptr(cov)
+    a.viewmatrix, a.projmatrix, a.campos = ptr(view), ptr(proj), ptr(campos)
+    a.out_color, a.out_depth, a.out_alpha, a.radii = ptr(color), ptr(depth), ptr(alpha), ptr(radii)
+    a.group_ids, a.num_groups = ptr(group_ids), G
+    return a
+
+
+def _streaming_render(a: OgsRasterFwdArgs, dev, lib, debug: bool):
+    """The two-phase forward (geometry -> num_rendered -> render) on the buffers `a` already points to for inputs
+    and outputs; allocates and returns (geom, image, point_list, sorted_rec, quad_list, num_rendered)."""
+    P, W, H, Cn, G = int(a.P), int(a.W), int(a.H), int(a.C), max(int(a.num_groups), 1)
+    u8 = lambda n: torch.empty(int(n), dtype=torch.uint8, device=dev)
+    geom = u8(lib.ogs_raster_geom_bytes(P, Cn))
+    geom_tmp = u8(lib.ogs_raster_geom_tmp_bytes(P))
+    image = u8(lib.ogs_raster_image_bytes_grouped(W, H, G))
+    a.geom_buffer, a.geom_tmp, a.image_buffer = ptr(geom), ptr(geom_tmp), ptr(image)
+    stream = _stream()
+
+    def alloc_render(count):
+        pl = torch.empty(max(count, 1), dtype=torch.int32, device=dev)
+        bt = u8(lib.ogs_raster_binning_tmp_bytes(count, W, H))
+        sr = u8(lib.ogs_raster_sorted_bytes(count, Cn))
+        ql = u8(lib.ogs_raster_quad_list_bytes(count))
+        a.point_list, a.binning_tmp, a.sorted_rec, a.quad_list = ptr(pl), ptr(bt), ptr(sr), ptr(ql)
+        return pl, bt, sr, ql
+
+    key = (P, W, H, G)
+    # grouped passes: num_rendered follows the group ids of the call (cluster chunk, leaf range), which change
+    # from call to call -> sized by the blocking read-back, like subset passes (their P is new every time)
+    cap = None if (G > 1 or debug) else _hint_capacity(key)
+    if cap is None:
+        PASS_STATS["blocking"] += 1
+        # first pass at this size: blocking 4-byte read-back of num_rendered (what the reference does every time)
+        n = C.c_int64(0)
+        check(lib.ogs_raster_forward_geometry(C.byref(a), stream, C.byref(n)), "ogs_raster_forward_geometry")
+        D = int(n.value)
+        point_list, bin_tmp, sorted_rec, quad_list = alloc_render(D)
+        check(lib.ogs_raster_forward_render(C.byref(a), D, stream), "ogs_raster_forward_render")
+    else:
+        # steady state: no GPU idle gap.  The render phase is enqueued for a capacity derived from the recent
+        # passes at this size; the true count arrives through an async pinned copy and is only WAITED for after
+        # everything is queued.  Overflow (scene changed a lot) -> redo the render phase with exact buffers.
+        check(lib.ogs_raster_forward_geometry(C.byref(a), stream, None), "ogs_raster_forward_geometry")
+        pinned, ev = _readback_slot(dev)
+        check(lib.ogs_raster_read_num_rendered_async(C.byref(a), stream, pinned.data_ptr()),
+              "ogs_raster_read_num_rendered_async")
+        ev.record()
+        PASS_STATS["deferred"] += 1
+        point_list, bin_tmp, sorted_rec, quad_list = alloc_render(cap)
+        check(lib.ogs_raster_forward_render_deferred(C.byref(a), cap, stream), "ogs_raster_forward_render_deferred")
+        ev.synchronize()
+        D = int(pinned.item()) & 0xFFFFFFFF
+        if D > cap:
+            PASS_STATS["overflow"] += 1
+            point_list, bin_tmp, sorted_rec, quad_list = alloc_render(D)
+            check(lib.ogs_raster_forward_render(C.byref(a), D, stream), "ogs_raster_forward_render")
+    _hint_record(key, D)
+    return geom, image, point_list, sorted_rec, quad_list, D
 
 
 class _RasterizeGaussians(torch.autograd.Function):
@@ -164,73 +236,29 @@ class _RasterizeGaussians(torch.autograd.Function):
         alpha = alloc(*lead, 1, H, W, dtype=torch.float32, device=dev)
         radii = alloc(P, dtype=torch.int32, device=dev)
         ctx.raster_settings = rs
-        ctx.P, ctx.Cn, ctx.num_rendered = P, Cn, 0
+        ctx.P, ctx.Cn, ctx.num_rendered, ctx.tiny = P, Cn, 0, False
         if P == 0:
             # reference behaviour: zero images, nothing launched (SURVEY.md section 8(b) "Errors")
             ctx.save_for_backward()
             ctx.mark_non_differentiable(radii)
             return color, radii, depth, alpha
 
-        u8 = lambda n: torch.empty(int(n), dtype=torch.uint8, device=dev)
-        geom = u8(lib.ogs_raster_geom_bytes(P, Cn))
-        geom_tmp = u8(lib.ogs_raster_geom_tmp_bytes(P))
-        image = u8(lib.ogs_raster_image_bytes_grouped(W, H, G))
+        a = _fwd_args(rs, P, Cn, m3, shs, cols, opac, scl, rot, cov, bg, view, proj, campos, color, depth, alpha, radii,
+                      group_ids, G)
 
-        a = OgsRasterFwdArgs()
-        a.P, a.W, a.H, a.C = P, W, H, Cn
-        a.sh_degree = int(rs.sh_degree)
-        a.sh_coeffs = 0 if shs is None else int(shs.shape[1])
-        a.tanfovx, a.tanfovy, a.scale_modifier = float(rs.tanfovx), float(rs.tanfovy), float(rs.scale_modifier)
-        a.prefiltered, a.debug = int(bool(rs.prefiltered)), int(bool(rs.debug))
-        a.bg, a.means3D, a.colors_precomp, a.shs, a.opacities = ptr(bg), ptr(m3), ptr(cols), ptr(shs), ptr(opac)
-        a.scales, a.rotations, a.cov3D_precomp = ptr(scl), ptr(rot), ptr(cov)
-        a.viewmatrix, a.projmatrix, a.campos = ptr(view), ptr(proj), ptr(campos)
-        a.out_color, a.out_depth, a.out_alpha, a.radii = ptr(color), ptr(depth), ptr(alpha), ptr(radii)
-        a.geom_buffer, a.geom_tmp, a.image_buffer = ptr(geom), ptr(geom_tmp), ptr(image)
-        a.group_ids, a.num_groups = ptr(group_ids), G
+        if G == 1 and not rs.debug and P <= min(TINY_MAX_P, int(lib.ogs_raster_tiny_max_points())):
+            # tiny pass: two launches, no read-back, nothing kept -- backward() re-renders through the streaming path
+            u8 = lambda n: torch.empty(int(n), dtype=torch.uint8, device=dev)
+            geom, geom_tmp = u8(lib.ogs_raster_geom_bytes(P, Cn)), u8(lib.ogs_raster_geom_tmp_bytes(P))
+            a.geom_buffer, a.geom_tmp = ptr(geom), ptr(geom_tmp)
+            check(lib.ogs_raster_forward_tiny(C.byref(a), _stream()), "ogs_raster_forward_tiny")
+            PASS_STATS["tiny"] += 1
+            ctx.tiny, ctx.num_rendered = True, -1
+            ctx.save_for_backward(m3, shs, cols, opac, scl, rot, cov, bg, view, proj, campos, radii, alpha)
+            ctx.mark_non_differentiable(radii)
+            return color, radii, depth, alpha
 
-        stream = _stream()
-
-        def alloc_render(count):
-            pl = torch.empty(max(count, 1), dtype=torch.int32, device=dev)
-            bt = u8(lib.ogs_raster_binning_tmp_bytes(count, W, H))
-            sr = u8(lib.ogs_raster_sorted_bytes(count, Cn))
-            ql = u8(lib.ogs_raster_quad_list_bytes(count))
-            a.point_list, a.binning_tmp, a.sorted_rec, a.quad_list = ptr(pl), ptr(bt), ptr(sr), ptr(ql)
-            return pl, bt, sr, ql
-
-        key = (P, W, H, G)
-        # grouped passes: num_rendered follows the group ids of the call (cluster chunk, leaf range), which change
-        # from call to call -> sized by the blocking read-back, like subset passes (their P is new every time)
-        cap = None if (G > 1 or rs.debug) else _hint_capacity(key)
-        if cap is None:
-            PASS_STATS["blocking"] += 1
-            # first pass at this size: blocking 4-byte read-back of num_rendered (what the reference does every time)
-            n = C.c_int64(0)
-            check(lib.ogs_raster_forward_geometry(C.byref(a), stream, C.byref(n)), "ogs_raster_forward_geometry")
-            D = int(n.value)
-            point_list, bin_tmp, sorted_rec, quad_list = alloc_render(D)
-            check(lib.ogs_raster_forward_render(C.byref(a), D, stream), "ogs_raster_forward_render")
-        else:
-            # steady state: no GPU idle gap.  The render phase is enqueued for a capacity derived from the last
-            # pass at this size; the true count arrives through an async pinned copy and is only WAITED for after
-            # everything is queued.  Overflow (scene changed a lot) -> redo the render phase with exact buffers.
-            check(lib.ogs_raster_forward_geometry(C.byref(a), stream, None), "ogs_raster_forward_geometry")
-            pinned, ev = _readback_slot(dev)
-            check(lib.ogs_raster_read_num_rendered_async(C.byref(a), stream, pinned.data_ptr()),
-                  "ogs_raster_read_num_rendered_async")
-            ev.record()
-            PASS_STATS["deferred"] += 1
-            point_list, bin_tmp, sorted_rec, quad_list = alloc_render(cap)
-            check(lib.ogs_raster_forward_render_deferred(C.byref(a), cap, stream), "ogs_raster_forward_render_deferred")
-            ev.synchronize()
-            D = int(pinned.item()) & 0xFFFFFFFF
-            if D > cap:
-                PASS_STATS["overflow"] += 1
-                point_list, bin_tmp, sorted_rec, quad_list = alloc_render(D)
-                check(lib.ogs_raster_forward_render(C.byref(a), D, stream), "ogs_raster_forward_render")
-        _hint_record(key, D)
-
+        geom, image, point_list, sorted_rec, quad_list, D = _streaming_render(a, dev, lib, rs.debug)
         ctx.num_rendered = D
         ctx.save_for_backward(m3, shs, cols, opac, scl, rot, cov, bg, view, proj, campos, radii, alpha, geom, image,
                               point_list, sorted_rec, quad_list)
@@ -243,11 +271,23 @@ class _RasterizeGaussians(torch.autograd.Function):
         P, Cn = ctx.P, ctx.Cn
         if P == 0:
             return (None,) * 13
-        (m3, shs, cols, opac, scl, rot, cov, bg, view, proj, campos, radii, alpha, geom, image,
-         point_list, sorted_rec, quad_list) = ctx.saved_tensors
-        dev = m3.device
         lib = _lib.lib()
         H, W = int(rs.image_height), int(rs.image_width)
+        if ctx.tiny:
+            # a tiny pass keeps nothing: re-render through the streaming path (scratch outputs) to obtain the binning
+            # and blend state the backward kernels read.  Rare: the refiner's footprint renders never call backward.
+            (m3, shs, cols, opac, scl, rot, cov, bg, view, proj, campos, radii, alpha) = ctx.saved_tensors
+            dev = m3.device
+            e = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
+            a = _fwd_args(rs, P, Cn, m3, shs, cols, opac, scl, rot, cov, bg, view, proj, campos, e(Cn, H, W), e(1, H, W),
+                          e(1, H, W), torch.empty(P, dtype=torch.int32, device=dev), None, 1)
+            geom, image, point_list, sorted_rec, quad_list, D = _streaming_render(a, dev, lib, False)
+            ctx.num_rendered = D
+            PASS_STATS["tiny_rerendered_for_backward"] += 1
+        else:
+            (m3, shs, cols, opac, scl, rot, cov, bg, view, proj, campos, radii, alpha, geom, image,
+             point_list, sorted_rec, quad_list) = ctx.saved_tensors
+        dev = m3.device
         need = ctx.needs_input_grad   # means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D
         z = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
 

@@ -64,7 +64,7 @@ def _knn_mean_filter(points: torch.Tensor) -> torch.Tensor:
 
 
 def _render_subsets(group_of_point: torch.Tensor, num_groups: int, min_points: int, raster_settings, means3D,
-                    means2D, opacity, scales, rotations, cov3D_precomp, colors=None, shs=None):
+                    means2D, opacity, scales, rotations, cov3D_precomp, colors=None, shs=None, groups_per_pass=None):
     """Images of the subsets {p : group_of_point[p] == g} with at least `min_points` members, in ONE grouped
     rasterizer pass per GROUPS_PER_PASS subsets instead of one boolean-indexed call each (the reference's
     per-cluster loops, :203-225,327-345).  Returns (kept group numbers, colour list [C,H,W], alpha list [1,H,W])."""
@@ -73,8 +73,9 @@ def _render_subsets(group_of_point: torch.Tensor, num_groups: int, min_points: i
     kept = torch.nonzero(counts >= min_points).flatten()
     kept_list = kept.tolist()
     imgs, sils = [], []
-    for c0 in range(0, len(kept_list), GROUPS_PER_PASS):
-        chunk = kept[c0:c0 + GROUPS_PER_PASS]
+    step = int(groups_per_pass or GROUPS_PER_PASS)
+    for c0 in range(0, len(kept_list), step):
+        chunk = kept[c0:c0 + step]
         remap = torch.full((num_groups + 1,), -1, dtype=torch.int32, device=group_of_point.device)
         remap[chunk] = torch.arange(chunk.numel(), dtype=torch.int32, device=group_of_point.device)
         local = remap[torch.where(valid, group_of_point, torch.full_like(group_of_point, num_groups))]
@@ -206,6 +207,11 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, iteration,
                 rendered_ins_feat = torch.cat(parts, dim=0)
 
     # ---- [Stage 2.2 preprocessing] coarse cluster feature maps (:168-236) ---------------------------------
+    # Both cluster blocks below reduce to "label every Gaussian with the subset it is rendered in (-1: none), then
+    # render all subsets": _render_subsets does that in grouped passes (BATCH_SUBSETS) or, with one group per pass,
+    # as the reference's one rasterizer call per boolean-indexed subset.
+    per_pass = GROUPS_PER_PASS if BATCH_SUBSETS else 1
+    none_of = lambda t: torch.full_like(t, -1)
     viewed_pts = radii > 0
     if cluster_idx is not None:
         num_cluster = cluster_idx.max() + 1
@@ -216,41 +222,25 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, iteration,
         ins_feat = (pc.get_ins_feat(origin=origin_feat) + 1) / 2
         rendered_clusters = []
         rendered_cluster_silhouettes = []
-        scale_filter = (scales < 0.5).all(dim=1)
-        if better_vis and BATCH_SUBSETS:
-            # every coarse cluster is rendered (:179-201): one grouped pass instead of num_cluster subset calls
-            gid = torch.where(viewed_pts & scale_filter, cluster_idx.to(torch.int64), torch.full_like(cluster_idx, -1, dtype=torch.int64))
-            if viewpoint_camera.bClusterOccur is not None:
-                occ = torch.as_tensor(viewpoint_camera.bClusterOccur).to(device=gid.device, dtype=torch.bool)
-                gid = torch.where(occ[gid.clamp_min(0)], gid, torch.full_like(gid, -1))
-            kept, imgs, sils = _render_subsets(gid, int(num_cluster), 100, raster_settings, means3D, means2D, opacity,
-                                               None if scales is None else scales * rescale_factor, rotations,
-                                               cov3D_precomp, colors=ins_feat)
-            if sils:
-                seen = (torch.stack([s_.max() for s_ in sils]) > 0.8).tolist()
-                for idx, img, sil, ok in zip(kept, imgs, sils, seen):
-                    if ok:
-                        cluster_occur[idx] = True
-                        rendered_clusters.append(img)
-                        rendered_cluster_silhouettes.append(sil)
-        for idx in ([] if (better_vis and BATCH_SUBSETS) else range(num_cluster)):
-            if not better_vis and idx != selected_root_id:
-                continue
-            if viewpoint_camera.bClusterOccur is not None and viewpoint_camera.bClusterOccur[idx] == False:  # noqa: E712
-                continue
-            filter_idx = (cluster_idx == idx) & viewed_pts
-            if better_vis:
-                filter_idx = filter_idx & scale_filter
-                if filter_idx.sum() < 100:
-                    continue
-            rendered_cluster, _, _, cluster_silhouette = rasterizer(
-                means3D=means3D[filter_idx], means2D=means2D[filter_idx], shs=None,
-                colors_precomp=ins_feat[filter_idx], opacities=opacity[filter_idx],
-                scales=scales[filter_idx] * rescale_factor, rotations=rotations[filter_idx], cov3D_precomp=cov3D_precomp)
-            if cluster_silhouette.max() > 0.8:
-                cluster_occur[idx] = True
-                rendered_clusters.append(rendered_cluster)
-                rendered_cluster_silhouettes.append(cluster_silhouette)
+        gid = torch.where(viewed_pts, cluster_idx.to(torch.int64), none_of(cluster_idx).to(torch.int64))
+        if better_vis:
+            # every coarse cluster, small Gaussians only, at least 100 of them (:186-189)
+            gid = torch.where((scales < 0.5).all(dim=1), gid, none_of(gid))
+        else:
+            gid = torch.where(gid == selected_root_id, gid, none_of(gid))       # the selected one only (:180-181)
+        if viewpoint_camera.bClusterOccur is not None:                           # clusters this camera never sees (:182-183)
+            occ = torch.as_tensor(viewpoint_camera.bClusterOccur).to(device=gid.device, dtype=torch.bool)
+            gid = torch.where(occ[gid.clamp_min(0)], gid, none_of(gid))
+        kept, imgs, sils = _render_subsets(gid, int(num_cluster), 100 if better_vis else 1, raster_settings, means3D,
+                                           means2D, opacity, None if scales is None else scales * rescale_factor,
+                                           rotations, cov3D_precomp, colors=ins_feat, groups_per_pass=per_pass)
+        if sils:
+            seen = (torch.stack([s_.max() for s_ in sils]) > 0.8).tolist()      # one read-back for all clusters
+            for idx, img, sil, ok in zip(kept, imgs, sils, seen):
+                if ok:
+                    cluster_occur[idx] = True
+                    rendered_clusters.append(img)
+                    rendered_cluster_silhouettes.append(sil)
         if len(rendered_cluster_silhouettes) != 0:
             rendered_cluster_silhouettes = torch.vstack(rendered_cluster_silhouettes)
     else:
@@ -259,80 +249,43 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, iteration,
     # ---- [Stage 2.2 & 3] fine cluster feature maps (:239-356) --------------------------------------------------
     if leaf_cluster_idx is not None and leaf_cluster_idx.numel() > 0:
         ins_feat = (pc.get_ins_feat(origin=origin_feat) + 1) / 2
-        scale_filter = (scales < 0.1).all(dim=1)
         rendered_leaf_clusters = []
         rendered_leaf_cluster_silhouettes = []
         occured_leaf_id = []
-        if selected_leaf_id is None:
-            if selected_root_id is not None:
-                start_leaf = selected_root_id * leaf_num
-                end_leaf = start_leaf + leaf_num
-            else:
-                start_leaf = 0
-                end_leaf = root_num * leaf_num
-            lerf_range = range(start_leaf, end_leaf)
+        lid = leaf_cluster_idx.to(torch.int64)
+        if selected_leaf_id is not None:
+            # the listed leaves rendered TOGETHER as one subset, reported under the first listed id (:287-289,317-318)
+            first_leaf = int(selected_leaf_id.flatten()[0])
+            n_sub, sub_base = 1, first_leaf
+            gid = torch.where((lid.unsqueeze(1) == selected_leaf_id.to(lid.device)).any(dim=1), torch.zeros_like(lid), none_of(lid))
         else:
-            lerf_range = selected_leaf_id.tolist()
-        root_seen = not (viewpoint_camera.bClusterOccur is not None and selected_root_id is not None and
-                         viewpoint_camera.bClusterOccur[selected_root_id] == False)  # noqa: E712
-        batched = BATCH_SUBSETS and selected_leaf_id is None and not post_process
-        if batched and root_seen and not (viewpoint_camera.bClusterOccur is not None and selected_root_id is None):
-            # all leaves of the range in grouped passes (:245-356 without the per-leaf Python loop)
-            n_leaf = end_leaf - start_leaf
-            lid = leaf_cluster_idx.to(torch.int64) - start_leaf
-            ok_pt = (lid >= 0) & (lid < n_leaf) & viewed_pts
-            if pre_mask is not None:
-                ok_pt = ok_pt & pre_mask
-            if better_vis:
-                ok_pt = ok_pt & scale_filter
-            gid = torch.where(ok_pt, lid, torch.full_like(lid, -1))
-            min_pts = 100 if better_vis else 10
-            kept, imgs, sils = _render_subsets(gid, n_leaf, min_pts, raster_settings, means3D, means2D, opacity, scales,
-                                               rotations, cov3D_precomp, colors=None if seg_rgb else ins_feat,
-                                               shs=shs if seg_rgb else None)
-            for k_, img, sil in zip(kept, imgs, sils):
-                occured_leaf_id.append(start_leaf + k_)
-                if seg_rgb and ins_feat.shape[-1] > 3:
-                    img = torch.cat((img, img), dim=0)
-                rendered_leaf_clusters.append(img)
-                rendered_leaf_cluster_silhouettes.append(sil)
-            lerf_range = []
-        for _, leaf_idx in enumerate(lerf_range):
-            if viewpoint_camera.bClusterOccur is not None and viewpoint_camera.bClusterOccur[selected_root_id] == False:  # noqa: E712
-                continue
-            if selected_leaf_id is None:
-                filter_idx = leaf_cluster_idx == leaf_idx
-            else:
-                filter_idx = (leaf_cluster_idx.unsqueeze(1) == selected_leaf_id).any(dim=1)
-            if pre_mask is not None:
-                filter_idx = filter_idx & pre_mask
-            filter_idx = filter_idx & viewed_pts
-            if better_vis:
-                filter_idx = filter_idx & scale_filter
-                if filter_idx.sum() < 100:
-                    continue
-            if post_process:
-                mask = _knn_mean_filter(means3D[filter_idx])
-                filter_idx[filter_idx != 0] = mask
-            if filter_idx.sum() < 10:
-                continue
-            occured_leaf_id.append(leaf_idx)
-            if seg_rgb:
-                rendered_leaf_cluster, _, _, leaf_cluster_silhouette = rasterizer(
-                    means3D=means3D[filter_idx], means2D=means2D[filter_idx], shs=shs[filter_idx], colors_precomp=None,
-                    opacities=opacity[filter_idx], scales=scales[filter_idx], rotations=rotations[filter_idx],
-                    cov3D_precomp=cov3D_precomp)
-                if ins_feat.shape[-1] > 3:      # the reference renders the same RGB twice and stacks it (:336-346)
-                    rendered_leaf_cluster = torch.cat((rendered_leaf_cluster, rendered_leaf_cluster), dim=0)
-            else:
-                rendered_leaf_cluster, _, _, leaf_cluster_silhouette = rasterizer(
-                    means3D=means3D[filter_idx], means2D=means2D[filter_idx], shs=None,
-                    colors_precomp=ins_feat[filter_idx], opacities=opacity[filter_idx], scales=scales[filter_idx],
-                    rotations=rotations[filter_idx], cov3D_precomp=cov3D_precomp)
-            rendered_leaf_clusters.append(rendered_leaf_cluster)
-            rendered_leaf_cluster_silhouettes.append(leaf_cluster_silhouette)
-            if selected_leaf_id is not None and len(rendered_leaf_clusters) > 0:
-                break
+            start_leaf = selected_root_id * leaf_num if selected_root_id is not None else 0
+            n_sub = leaf_num if selected_root_id is not None else root_num * leaf_num
+            sub_base = start_leaf
+            gid = torch.where((lid >= start_leaf) & (lid < start_leaf + n_sub), lid - start_leaf, none_of(lid))
+        occ = viewpoint_camera.bClusterOccur
+        if occ is not None and occ[selected_root_id] == False:                   # noqa: E712  (:284-285; indexing with
+            gid = none_of(gid)                                                   # None keeps the reference's behaviour)
+        if pre_mask is not None:
+            gid = torch.where(pre_mask, gid, none_of(gid))
+        gid = torch.where(viewed_pts, gid, none_of(gid))
+        if better_vis:                                                           # small Gaussians, >= 100 per leaf (:293-296)
+            gid = torch.where((scales < 0.1).all(dim=1), gid, none_of(gid))
+            cnt = torch.bincount(gid[gid >= 0], minlength=n_sub)
+            gid = torch.where((cnt >= 100)[gid.clamp_min(0)], gid, none_of(gid))
+        if post_process:                                                         # per-leaf kNN outlier filter (:297-309)
+            for g_ in torch.unique(gid[gid >= 0]).tolist():
+                rows = torch.nonzero(gid == g_).flatten()
+                gid[rows[~_knn_mean_filter(means3D[rows])]] = -1
+        kept, imgs, sils = _render_subsets(gid, n_sub, 10, raster_settings, means3D, means2D, opacity, scales, rotations,
+                                           cov3D_precomp, colors=None if seg_rgb else ins_feat,
+                                           shs=shs if seg_rgb else None, groups_per_pass=per_pass)
+        for k_, img, sil in zip(kept, imgs, sils):
+            occured_leaf_id.append(sub_base + k_)
+            if seg_rgb and ins_feat.shape[-1] > 3:      # the reference renders the same RGB twice and stacks it (:336-346)
+                img = torch.cat((img, img), dim=0)
+            rendered_leaf_clusters.append(img)
+            rendered_leaf_cluster_silhouettes.append(sil)
         if len(rendered_leaf_cluster_silhouettes) != 0:
             rendered_leaf_cluster_silhouettes = torch.vstack(rendered_leaf_cluster_silhouettes)
     else:

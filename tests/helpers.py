@@ -49,8 +49,21 @@ def settings_for(cam, bg, sh_degree, device, debug=False):
         sh_degree=sh_degree, campos=cam.camera_center.to(device), prefiltered=False, debug=debug)
 
 
-def hip_forward(inp, cam, bg, sh_degree, device, requires_grad=False, debug=False):
-    """Run GaussianRasterizer on `device` with the same arrays as the oracle.  Returns (outputs, leaves)."""
+def hip_forward(inp, cam, bg, sh_degree, device, requires_grad=False, debug=False, tiny=False):
+    """Run GaussianRasterizer on `device` with the same arrays as the oracle.  Returns (outputs, leaves).
+    tiny=False forces the streaming path even for P <= TINY_MAX_P (callers export its binning state)."""
+    from opengaussian_amd import rasterizer as R
+    from opengaussian_amd.rasterizer import GaussianRasterizer
+    saved = R.TINY_MAX_P
+    if not tiny:
+        R.TINY_MAX_P = 0
+    try:
+        return _hip_forward(inp, cam, bg, sh_degree, device, requires_grad, debug)
+    finally:
+        R.TINY_MAX_P = saved
+
+
+def _hip_forward(inp, cam, bg, sh_degree, device, requires_grad, debug):
     from opengaussian_amd.rasterizer import GaussianRasterizer
     t = lambda k: (None if inp.get(k) is None else
                    torch.tensor(np.asarray(inp[k]), dtype=torch.float32, device=device, requires_grad=requires_grad))
@@ -111,35 +124,44 @@ KM_TIE = 1e-5          # ids exact except rows whose bes
 KM_CENTER_TOL = 1e-4   # north_star tolerance on centres
 
 
-def kmeans_step_attribution(feat, c_prev, c_next_ref, ids_prev_ref, ids_prev_got, c_next_got, what=""):
-    """ONE Lloyd iteration started from the REFERENCE's centres ``c_prev`` (so a near-tie flip cannot cascade):
+def kmeans_step_attribution(feat, c_prev, c_next_ref, ids_prev_ref, ids_prev_got, c_next_got, what="", c_prev_got=None):
+    """ONE Lloyd iteration, the reference's (from its centres ``c_prev``) against the one under test (from
+    ``c_prev_got``; default: the same centres, so that a near-tie flip cannot cascade):
 
-    * every id that differs from the float64 nearest centre -- in the result under test AND in the reference's own
-      trajectory (its cdist goes through a matmul) -- must sit on a near tie: the distance to the chosen centre
-      exceeds the float64 minimum by < KM_TIE;
-    * the centres under test must equal the float64 mean of THEIR OWN members to 2e-5 (pure arithmetic);
-    * against the reference's next centres ``c_next_ref``: a cluster whose membership is identical on both sides
-      must agree to KM_CENTER_TOL; a cluster that gained / lost near-tie rows may move by at most the sum of
-      those rows' offsets |x - c| / n on top of that -- every centre difference is attributed to named rows.
-    Returns the number of near-tie rows involved (for the log)."""
+    * arithmetic: every id -- of the result under test under ITS centres, of the reference's own trajectory under
+      the reference's (its cdist goes through a matmul) -- is the float64 nearest centre up to a tie: the distance to
+      the chosen centre exceeds the float64 minimum by < KM_TIE;
+    * attribution of ids: where the two sides chose differently, the two candidate centres are within
+      2 * KM_TIE + 2 * delta of each other for that row (delta = max difference of the previous centres: it
+      shifts every distance by at most delta);
+    * the centres under test equal the float64 mean of THEIR OWN members to 2e-5 (pure arithmetic);
+    * attribution of centres: a cluster whose membership is identical on both sides agrees with the reference's next
+      centre to KM_CENTER_TOL; one that gained / lost flipped rows may move by at most the sum of those rows'
+      offsets |x - c| / n on top of that.
+    Returns (number of flipped rows, max difference of the next centres)."""
     X = np.asarray(feat, np.float64)
     C = np.asarray(c_prev, np.float64)
-    d = np.sqrt(((X[:, None, :] - C[None, :, :]) ** 2).sum(-1))
-    best = d.argmin(1)
-    dmin = d[np.arange(len(X)), best]
-    for name, ids in (("under test", ids_prev_got), ("reference", ids_prev_ref)):
+    Cg = C if c_prev_got is None else np.asarray(c_prev_got, np.float64)
+    delta = float(np.abs(Cg - C).max())
+    dist = lambda cc: np.sqrt(((X[:, None, :] - cc[None, :, :]) ** 2).sum(-1))
+    d_ref = dist(C)
+    d_got = d_ref if c_prev_got is None else dist(Cg)
+    rows = np.arange(len(X))
+    for name, ids, d in (("under test", ids_prev_got, d_got), ("reference", ids_prev_ref, d_ref)):
         if ids is None:
             continue
         ids = np.asarray(ids, np.int64)
-        bad = np.nonzero(ids != best)[0]
-        excess = d[bad, ids[bad]] - dmin[bad]
-        assert (excess < KM_TIE).all(), (f"{what}: {name} ids differ from the f64 nearest centre on rows that are NOT near "
-                                         f"ties: rows {bad[excess >= KM_TIE][:5]} excess {excess.max()}")
+        excess = d[rows, ids] - d.min(1)
+        assert (excess < KM_TIE).all(), (f"{what}: {name} ids are not the f64 nearest centre on rows that are NOT near ties: "
+                                         f"rows {np.nonzero(excess >= KM_TIE)[0][:5]} excess {excess.max()}")
     got = np.asarray(ids_prev_got, np.int64)
-    ref = best if ids_prev_ref is None else np.asarray(ids_prev_ref, np.int64)
+    ref = d_ref.argmin(1) if ids_prev_ref is None else np.asarray(ids_prev_ref, np.int64)
     k = C.shape[0]
     cg, cr = np.asarray(c_next_got, np.float64), np.asarray(c_next_ref, np.float64)
     flipped = np.nonzero(got != ref)[0]
+    gap = np.abs(d_ref[flipped, got[flipped]] - d_ref[flipped, ref[flipped]])
+    assert (gap < 2 * KM_TIE + 2 * delta).all(), (f"{what}: ids differ on rows whose candidate centres are NOT within "
+                                                  f"2*{KM_TIE} + 2*{delta:.2e}: rows {flipped[gap >= 2 * KM_TIE + 2 * delta][:5]}")
     for j in range(k):
         members = got == j
         n = int(members.sum())
@@ -151,8 +173,8 @@ def kmeans_step_attribution(feat, c_prev, c_next_ref, ids_prev_ref, ids_prev_got
         touching = flipped[(got[flipped] == j) | (ref[flipped] == j)]
         allowed = KM_CENTER_TOL + sum(np.abs(X[r] - cr[j]).max() for r in touching) / max(min(n, int((ref == j).sum())), 1)
         assert np.abs(cg[j] - cr[j]).max() <= allowed, (f"{what}: centre {j} off by {np.abs(cg[j] - cr[j]).max()} with "
-                                                          f"{len(touching)} near-tie rows touching it (allowed {allowed})")
-    return len(flipped)
+                                                          f"{len(touching)} flipped rows touching it (allowed {allowed})")
+    return len(flipped), float(np.abs(cg - cr).max())
 
 
 def kmeans_final_ids_attribution(feat, c_ref, ids_ref, c_got, ids_got, what=""):

@@ -194,6 +194,7 @@ def test_backward_parity(gpu_device, use_sh, use_cov, seed):
     sc, cam = helpers.tiny_scene(1500, W, H, f, seed=seed)
     inp = helpers.oracle_inputs(sc, cam, use_sh=use_sh, use_cov=use_cov)
     errs = _grad_check(inp, cam, W, H, f, gpu_device, seed=seed)
+    print("backward_parity", use_sh, use_cov, {k: f"{e:.1e}" for k, e in errs.items()})
     assert errs, "no gradients compared"
     for k, e in errs.items():
         assert e < GRAD_TOL, f"{k}: relative error {e} (all: {errs})"
@@ -339,6 +340,74 @@ def test_empty_and_degenerate(gpu_device):
     assert torch.equal(vis.cpu(), sc.means3D[:, 2] > 0.2)
 
 
+@pytest.mark.parametrize("P,W,H,use_sh", [(1, 96, 64, True), (2, 100, 77, False), (7, 33, 21, True), (63, 160, 96, True),
+                                          (64, 128, 80, False), (200, 320, 200, True), (256, 150, 90, True)])
+def test_tiny_pass_equals_streaming_path_and_oracle(gpu_device, P, W, H, use_sh):
+    """P <= 256 ungrouped passes take the two-launch tiny path (ogs_raster_forward_tiny: one workgroup preprocesses
+    + depth-sorts, one workgroup per tile collects its list and blends).  Images, depth, alpha and radii must
+    equal the streaming path's bit for bit and the oracle's to 1e-4; backward() on a tiny pass re-renders through
+    the streaming path and must give the streaming pass's gradients."""
+    from oracle import raster_oracle as ro
+    from opengaussian_amd import rasterizer as R
+    f = 0.9 * max(W, H)
+    sc, cam = helpers.tiny_scene(P, W, H, f, seed=300 + P, log_scale_mean=-2.5, with_ties=True)
+    inp = helpers.oracle_inputs(sc, cam, use_sh=use_sh, feat=None if use_sh else sc.ins_feat)
+    Cn = 3 if use_sh else 6
+    bg = (0.2, 0.1, 0.3)
+    st0 = dict(R.PASS_STATS)
+    (ct, rt, dt, at), lt = helpers.hip_forward(inp, cam, bg, 3, gpu_device, requires_grad=True, tiny=True)
+    assert R.PASS_STATS["tiny"] == st0["tiny"] + 1 and ct.grad_fn.tiny
+    (cs, rs_, ds, as_), ls = helpers.hip_forward(inp, cam, bg, 3, gpu_device, requires_grad=True, tiny=False)
+    assert R.PASS_STATS["tiny"] == st0["tiny"] + 1 and not cs.grad_fn.tiny
+    assert torch.equal(rt, rs_)
+    assert torch.equal(ct, cs) and torch.equal(dt, ds) and torch.equal(at, as_)
+    ref = ro.render_forward(W=W, H=H, tanfovx=W / (2 * f), tanfovy=H / (2 * f), bg=np.array((bg * 2)[:Cn], np.float32),
+                            sh_degree=3, **inp)
+    np.testing.assert_array_equal(rt.cpu().numpy(), ref["geom"].radii)
+    helpers.assert_close_modulo_threshold_flips(ct.detach().cpu().numpy(), ref["color"], IMG_TOL)
+    helpers.assert_close_modulo_threshold_flips(at.detach().cpu().numpy(), ref["alpha"], IMG_TOL)
+    helpers.assert_close_modulo_threshold_flips(dt.detach().cpu().numpy(), ref["depth"], IMG_TOL * 10, flip_tol=4e-2)
+    g = torch.Generator().manual_seed(P)
+    gC, gD, gA = (torch.randn(Cn, H, W, generator=g).to(gpu_device), torch.randn(1, H, W, generator=g).to(gpu_device),
+                  torch.randn(1, H, W, generator=g).to(gpu_device))
+    torch.autograd.backward([ct, dt, at], [gC, gD, gA])
+    assert R.PASS_STATS["tiny_rerendered_for_backward"] == st0["tiny_rerendered_for_backward"] + 1
+    torch.autograd.backward([cs, ds, as_], [gC, gD, gA])
+    for k in lt:
+        if lt[k] is None or lt[k].grad is None:
+            assert ls[k] is None or ls[k].grad is None, k
+            continue
+        assert torch.equal(lt[k].grad, ls[k].grad), k
+
+
+def test_single_gaussian_footprints_grouped_equals_p1_calls(gpu_device):
+    """The SAM refiner renders ONE Gaussian per call, for every Gaussian and camera
+    (utils/sam_refinement_utils.py:330-403: render_single_gaussian slices [idx:idx+1] and calls the rasterizer).  Two
+    ways through this library: N tiny P = 1 calls, or one grouped pass with group_ids = arange(N).  Same footprints."""
+    from opengaussian_amd import rasterizer as R
+    from opengaussian_amd.rasterizer import GaussianRasterizer, rasterize_groups
+    N, W, H, f = 48, 160, 112, 130.0
+    sc, cam = helpers.tiny_scene(N, W, H, f, seed=91, log_scale_mean=-2.0)
+    dev = gpu_device
+    st = helpers.settings_for(cam, (0.0, 0.0, 0.0), 3, dev)
+    t = {k: getattr(sc, k).to(dev) for k in ("means3D", "opacities", "scales", "rotations", "shs")}
+    with torch.no_grad():
+        color, radii, depth, alpha = rasterize_groups(t["means3D"], torch.zeros(N, 3, device=dev), t["opacities"],
+                                                      torch.arange(N, device=dev), N, st, shs=t["shs"], scales=t["scales"],
+                                                      rotations=t["rotations"])
+    rast = GaussianRasterizer(st)
+    tiny0 = R.PASS_STATS["tiny"]
+    seen = 0
+    for i in range(N):
+        m2 = torch.zeros(1, 3, device=dev, requires_grad=True)           # as the refiner does (never back-propagated)
+        c, r, d, a = rast(means3D=t["means3D"][i:i + 1], means2D=m2, opacities=t["opacities"][i:i + 1], shs=t["shs"][i:i + 1],
+                          scales=t["scales"][i:i + 1], rotations=t["rotations"][i:i + 1])
+        assert int(r[0]) == int(radii[i])
+        assert torch.equal(c.detach(), color[i]) and torch.equal(a.detach(), alpha[i]) and torch.equal(d.detach(), depth[i])
+        seen += int(a.max() > 0)
+    assert R.PASS_STATS["tiny"] == tiny0 + N and seen >= N // 2
+
+
 def _adversarial_scene(kind, P, W, H, f, seed):
     """Scenes built to stress one mechanism each (all compared against the oracle)."""
     g = torch.Generator().manual_seed(seed)
@@ -401,6 +470,7 @@ def test_adversarial_scenes_forward_and_backward(gpu_device, kind, P, W, H):
         scale = np.abs(want).max() + 1e-12
         # long blending chains (thousands of fp32 T recoveries per pixel) loosen the bound a little
         tol = 5e-3 if kind == "long_lists" else GRAD_TOL
+        print("adversarial", kind, k, f"{np.abs(got - want).max() / scale:.1e}")
         assert np.abs(got - want).max() / scale < tol, (kind, k, np.abs(got - want).max() / scale)
 
 

@@ -18,7 +18,7 @@ The fused 9-channel pass is held to what the reference's separate passes produce
 104-151, train.py:431-436): oracle pass A = RGB with every gradient family, oracle pass B = the 6 feature channels
 with gradient to the features only.
 Tolerances: integers exact; images 1e-4 (depth 1e-3: un-normalised sum of z*w, z <= 10) up to the documented
-exp-threshold flips; gradients 2e-3 of the family's max vs float64 autograd (helpers / test_10_raster_gpu.py)."""
+exp-threshold flips; gradients 2e-4 of the family's max vs float64 autograd."""
 import numpy as np
 import pytest
 import torch
@@ -28,14 +28,16 @@ from tests import helpers
 
 pytestmark = pytest.mark.gpu
 
-GRAD_TOL = 2e-3
+# measured 3e-6 .. 6e-5 on every family at every size once the backward starts from the forward's exact final
+# transmittance and accumulates in fp64 (the fp32 1 - alpha start alone cost ~1e-3 on saturated pixels)
+GRAD_TOL = 2e-4
 
 CONFIGS = {
     #        P          W     H     f      fused  sampled tiles
-    "C2": (100_000, 800, 800, 700.0, False, 48),
-    "C3": (500_000, 988, 731, 800.0, True, 24),
-    "C4": (2_000_000, 648, 484, 500.0, True, 10),
-    "S1M": (1_000_000, 1920, 1080, 1000.0, True, 24),
+    "C2": (100_000, 800, 800, 700.0, False, 128),
+    "C3": (500_000, 988, 731, 800.0, True, 64),
+    "C4": (2_000_000, 648, 484, 500.0, True, 24),
+    "S1M": (1_000_000, 1920, 1080, 1000.0, True, 64),
 }
 
 
