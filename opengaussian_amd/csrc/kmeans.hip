@@ -70,6 +70,34 @@ __device__ __forceinline__ int nearest_centre(const float* __restrict__ rows, in
     return best_id;
 }
 
+// Two points per lane (d compile-time): the nine subtract / multiply-add pairs of a centre are issued as PACKED fp32
+// ops (v_pk_add_f32 / v_pk_fma_f32: two fp32 results per lane and issue slot) over the register pair {x_a[j], x_b[j]}
+// with the centre coordinate -- an SGPR from a scalar load -- broadcast to both halves.  Per centre and point
+// ~11 VALU issue slots instead of ~21; every point still sees exactly the arithmetic of nearest_centre (same
+// operation order, one fma per term), so the ids are identical.
+typedef float v2f_km __attribute__((ext_vector_type(2)));
+template <int DT>
+__device__ __forceinline__ void nearest_centre2(const float* __restrict__ rows, int row_a, int row_b,
+                                                const float* __restrict__ cs, int k_active, int& id_a, int& id_b) {
+    v2f_km x[DT];
+#pragma unroll
+    for (int j = 0; j < DT; ++j) x[j] = v2f_km{rows[row_a * DT + j], rows[row_b * DT + j]};
+    float best_a = 3.4e38f, best_b = 3.4e38f;
+    id_a = 0; id_b = 0;
+#pragma unroll 4
+    for (int c = 0; c < k_active; ++c) {
+        const float* cc = cs + c * DT;
+        v2f_km s = {0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < DT; ++j) {
+            const v2f_km t = x[j] - v2f_km{cc[j], cc[j]};
+            s = __builtin_elementwise_fma(t, t, s);
+        }
+        if (s.x < best_a) { best_a = s.x; id_a = c; }
+        if (s.y < best_b) { best_b = s.y; id_b = c; }
+    }
+}
+
 // ---- MFMA path: CB blocks of 16 clusters (k <= 16*CB), d <= 15 ---------------------------------------------------
 // ACCUM: Lloyd iteration (partials only); otherwise final re-assignment (ids only)
 template <int CB, bool ACCUM, int DT>
@@ -77,11 +105,13 @@ __global__ __launch_bounds__(kBlock) void kmeans_mfma_pass_kernel(const float* _
                                                                   const float* __restrict__ centers, int k,
                                                                   int k_active, int64_t* __restrict__ ids_out,
                                                                   int64_t id_offset, float* __restrict__ partials) {
+    constexpr int PPL = DT > 0 ? 2 : 1;                 // points per lane
+    constexpr int ROWS = kBlock * PPL;                  // rows staged per trip
     extern __shared__ float smem[];
     float* cs = smem;                                   // [k*d] centres
-    float* rows = cs + k * d;                           // [256*d] staged rows
-    int* ids_s = reinterpret_cast<int*>(rows + kBlock * d);   // [256] ids of the staged rows (-1: no row)
-    float* wtab = reinterpret_cast<float*>(ids_s + kBlock);   // [4][CB*16][16] per-wave tables (ACCUM, epilogue)
+    float* rows = cs + k * d;                           // [ROWS*d] staged rows
+    int* ids_s = reinterpret_cast<int*>(rows + ROWS * d);     // [ROWS] ids of the staged rows (-1: no row)
+    float* wtab = rows;                                 // [4][CB*16][16] per-wave tables: epilogue only, reuses `rows`
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < k * d; i += kBlock) cs[i] = centers[i];
     floatx4 acc[CB];
@@ -90,25 +120,40 @@ __global__ __launch_bounds__(kBlock) void kmeans_mfma_pass_kernel(const float* _
     __syncthreads();
 
     const int kq = lane >> 4, j = lane & 15;            // MFMA operand coordinates of this lane
-    const int64_t nblk = (N + kBlock - 1) / kBlock;
+    const int64_t nblk = (N + ROWS - 1) / ROWS;
     for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-        const int64_t row0 = blk * kBlock;
-        const int nrows = (int)min((int64_t)kBlock, N - row0);
+        const int64_t row0 = blk * ROWS;
+        const int nrows = (int)min((int64_t)ROWS, N - row0);
         const float* src = feat + row0 * d;
         for (int i = tid; i < nrows * d; i += kBlock) rows[i] = src[i];
         __syncthreads();
-        int best_id = -1;
-        if (tid < nrows) {
-            best_id = nearest_centre<DT>(rows, tid, d, DT > 0 ? centers : cs, k_active);
-            if (!ACCUM) ids_out[row0 + tid] = (int64_t)best_id + id_offset;
+        if constexpr (PPL == 2) {
+            // rows tid and tid + 256: both halves of the register pairs always hold a valid row (a missing second
+            // row re-scores the first one), the surplus id is discarded
+            const int ra = min(tid, nrows - 1), rb = min(tid + kBlock, nrows - 1);
+            int ia, ib;
+            nearest_centre2<DT>(rows, ra, rb, centers, k_active, ia, ib);
+            if (!ACCUM) {
+                if (tid < nrows) ids_out[row0 + tid] = (int64_t)ia + id_offset;
+                if (tid + kBlock < nrows) ids_out[row0 + tid + kBlock] = (int64_t)ib + id_offset;
+            } else {
+                ids_s[tid] = tid < nrows ? ia : -1;
+                ids_s[tid + kBlock] = tid + kBlock < nrows ? ib : -1;
+            }
+        } else {
+            int best_id = -1;
+            if (tid < nrows) {
+                best_id = nearest_centre<DT>(rows, tid, d, DT > 0 ? centers : cs, k_active);
+                if (!ACCUM) ids_out[row0 + tid] = (int64_t)best_id + id_offset;
+            }
+            if (ACCUM) ids_s[tid] = best_id;
         }
         if (ACCUM) {
-            ids_s[tid] = best_id;
             __syncthreads();
-            // this wave folds its 64 points, 4 per MFMA
+            // this wave folds its ROWS / 4 points, 4 per MFMA
 #pragma unroll 4
-            for (int g = 0; g < 16; ++g) {
-                const int p = wave * 64 + g * 4 + kq;
+            for (int g = 0; g < ROWS / 16; ++g) {
+                const int p = wave * (ROWS / 4) + g * 4 + kq;
                 const int id = ids_s[p];
                 float b = 0.f;
                 if (id >= 0) b = j < d ? rows[p * d + j] : (j == d ? 1.0f : 0.f);
@@ -265,7 +310,7 @@ int check_dims(int64_t N, int d, int k) {
     return OGS_OK;
 }
 
-int pass_blocks(int64_t N) {
+int pass_blocks(int64_t N) {      // upper bound over both trip sizes (tmp sizing); workgroups grid-stride anyway
     const int64_t nblk = (N + kBlock - 1) / kBlock;
     return (int)(nblk < kMaxBlocks ? (nblk > 0 ? nblk : 1) : kMaxBlocks);
 }
@@ -275,8 +320,13 @@ int cluster_blocks(int d, int k) {       // 0: MFMA tiling not applicable
     return k <= 16 ? 1 : (k <= 64 ? 4 : 16);
 }
 
+inline int rows_per_trip(int d) { return (d == 6 || d == 9) ? 2 * kBlock : kBlock; }   // compile-time widths: 2 points per lane
 size_t mfma_lds(int d, int k, int CB, bool accum) {
-    return sizeof(float) * ((size_t)k * d + (size_t)kBlock * d + kBlock + (accum ? (size_t)4 * CB * 16 * 16 : 0));
+    const size_t rows = (size_t)rows_per_trip(d);
+    // staged rows + ids; the epilogue's per-wave tables reuse the rows region
+    const size_t body = rows * d + rows;
+    const size_t wtab = accum ? (size_t)4 * CB * 16 * 16 : 0;
+    return sizeof(float) * ((size_t)k * d + (body > wtab ? body : wtab));
 }
 size_t fallback_lds(int d, int k, bool accum) {
     return sizeof(float) * ((size_t)k * d + (size_t)kBlock * d + (accum ? (size_t)k * (d + 1) : 0));

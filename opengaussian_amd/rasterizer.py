@@ -93,10 +93,37 @@ def _stream() -> int:
 
 
 def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
-    """contiguous fp32 view/copy (inputs may be sliced / boolean-indexed views, :133,204-212)."""
+    """contiguous fp32 view/copy (inputs may be sliced / boolean-indexed views, :133,204-212).  Tensors that already
+    are contiguous fp32 pass through untouched: a tiny pass is all host overhead, every torch call counts."""
     if t is None or t.numel() == 0:
         return None
+    if t.dtype is torch.float32 and t.is_contiguous():
+        return t.detach() if t.requires_grad else t
     return t.detach().to(torch.float32).contiguous()
+
+
+_TINY_LIMIT = None
+_TINY_SCRATCH: dict = {}
+
+
+def _tiny_limit() -> int:
+    global _TINY_LIMIT
+    if _TINY_LIMIT is None:
+        _TINY_LIMIT = int(_lib.lib().ogs_raster_tiny_max_points())
+    return min(TINY_MAX_P, _TINY_LIMIT)
+
+
+def _tiny_scratch(dev, stream: int, lib):
+    """geom_buffer + geom_tmp of a tiny pass (<= 256 Gaussians, 12 channels: a few tens of KB), one pair per (device,
+    stream): both are dead when the two launches of the pass have run, and passes on one stream are ordered."""
+    key = (dev, stream)
+    sc = _TINY_SCRATCH.get(key)
+    if sc is None:
+        n = int(lib.ogs_raster_tiny_max_points())
+        sc = (torch.empty(int(lib.ogs_raster_geom_bytes(n, 12)), dtype=torch.uint8, device=dev),
+              torch.empty(int(lib.ogs_raster_geom_tmp_bytes(n)), dtype=torch.uint8, device=dev))
+        _TINY_SCRATCH[key] = sc
+    return sc
 
 
 def _require_gpu(t: torch.Tensor, name: str):
@@ -231,6 +258,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         # P > 0: the kernels write every pixel of every tile and every radius, so no fill pass is needed
         alloc = torch.zeros if P == 0 else torch.empty
         lead = (G,) if G > 1 else ()           # grouped pass: one image per group
+        # three separate tensors (not views of one allocation): callers may modify an output in place
         color = alloc(*lead, Cn, H, W, dtype=torch.float32, device=dev)
         depth = alloc(*lead, 1, H, W, dtype=torch.float32, device=dev)
         alpha = alloc(*lead, 1, H, W, dtype=torch.float32, device=dev)
@@ -246,12 +274,12 @@ class _RasterizeGaussians(torch.autograd.Function):
         a = _fwd_args(rs, P, Cn, m3, shs, cols, opac, scl, rot, cov, bg, view, proj, campos, color, depth, alpha, radii,
                       group_ids, G)
 
-        if G == 1 and not rs.debug and P <= min(TINY_MAX_P, int(lib.ogs_raster_tiny_max_points())):
+        if G == 1 and not rs.debug and P <= _tiny_limit():
             # tiny pass: two launches, no read-back, nothing kept -- backward() re-renders through the streaming path
-            u8 = lambda n: torch.empty(int(n), dtype=torch.uint8, device=dev)
-            geom, geom_tmp = u8(lib.ogs_raster_geom_bytes(P, Cn)), u8(lib.ogs_raster_geom_tmp_bytes(P))
-            a.geom_buffer, a.geom_tmp = ptr(geom), ptr(geom_tmp)
-            check(lib.ogs_raster_forward_tiny(C.byref(a), _stream()), "ogs_raster_forward_tiny")
+            stream = _stream()
+            geom, geom_tmp = _tiny_scratch(dev, stream, lib)
+            a.geom_buffer, a.geom_tmp = geom.data_ptr(), geom_tmp.data_ptr()
+            check(lib.ogs_raster_forward_tiny(C.byref(a), stream), "ogs_raster_forward_tiny")
             PASS_STATS["tiny"] += 1
             ctx.tiny, ctx.num_rendered = True, -1
             ctx.save_for_backward(m3, shs, cols, opac, scl, rot, cov, bg, view, proj, campos, radii, alpha)

@@ -183,9 +183,11 @@ def _grad_check(inp, cam, W, H, f, device, sh_degree=3, bg=(0.1, 0.2, 0.3), seed
     return out
 
 
-# max |hip - f64 autograd| / max |f64 autograd| per gradient family.  fp32 recomputation of T by division,
-# the 1/(det^2 + 1e-7) regulariser of A.5 and float atomics bound this at ~1e-4..1e-3, not 1e-7.
-GRAD_TOL = 2e-3
+# max |hip - f64 autograd| / max |f64 autograd| per gradient family.  Measured 1e-6 .. 1e-5 on these scenes since
+# the backward starts from the forward's exact final transmittance and accumulates the per-Gaussian record in
+# fp64 (round 1: ~1e-4 .. 1e-3 with T_final = 1 - alpha and fp32 atomics); what is left is the fp32 T recovery by
+# division and the 1/(det^2 + 1e-7) chain of A.5.
+GRAD_TOL = 2e-4
 
 
 @pytest.mark.parametrize("use_sh,use_cov,seed", [(True, False, 0), (False, False, 1), (True, True, 2)])
@@ -273,7 +275,7 @@ def test_deferred_render_phase_and_capacity_overflow(gpu_device):
     R._LAST_NUM_RENDERED[key].clear(); R._LAST_NUM_RENDERED[key].append(7)                                # overflow
     (c2, r2, d2, a2), _ = helpers.hip_forward(inp, cam, (0.1, 0.2, 0.3), 3, gpu_device, requires_grad=True)
     assert list(R._LAST_NUM_RENDERED[key]) == [7, D] and c2.grad_fn.num_rendered == D
-    assert {k: R.PASS_STATS[k] - stats0[k] for k in stats0} == {"blocking": 1, "deferred": 2, "overflow": 1}
+    assert {k: R.PASS_STATS[k] - stats0[k] for k in ("blocking", "deferred", "overflow")} == {"blocking": 1, "deferred": 2, "overflow": 1}
     for c, r, d, a in ((c1, r1, d1, a1), (c2, r2, d2, a2)):
         assert torch.equal(c, c0) and torch.equal(r, r0) and torch.equal(d, d0) and torch.equal(a, a0)
     k0 = helpers.hip_export_binning(c0)
@@ -469,7 +471,7 @@ def test_adversarial_scenes_forward_and_backward(gpu_device, kind, P, W, H):
         want = gref[k].reshape(got.shape)
         scale = np.abs(want).max() + 1e-12
         # long blending chains (thousands of fp32 T recoveries per pixel) loosen the bound a little
-        tol = 5e-3 if kind == "long_lists" else GRAD_TOL
+        tol = 2e-3 if kind == "long_lists" else GRAD_TOL
         print("adversarial", kind, k, f"{np.abs(got - want).max() / scale:.1e}")
         assert np.abs(got - want).max() / scale < tol, (kind, k, np.abs(got - want).max() / scale)
 
