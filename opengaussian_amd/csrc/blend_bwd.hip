@@ -4,15 +4,16 @@
 // BACK-TO-FRONT from its own last contributor, indices and records fetched with wave-uniform scalar loads:
 // no LDS, no barriers.
 // Per (pixel, Gaussian) the C+7 partial gradients are NOT sent to memory one float atomic each (the
-// reference's ~10 atomics per pair): the 64 lanes hold a 16-slot vector each, folded with a transposed
-// butterfly
-//     v_permlane32_swap (xor 32) -> v_permlane16_swap (xor 16) -> DPP row_ror:8 -> row_half_mirror
-//     -> two quad_perm adds
-// (~35 VALU for all 16 slots instead of 16 x 6 shuffle-adds) so that lane 4*s ends up with the wave total
-// of slot s.  One global_atomic_add_f32 wave-instruction with <=16 active lanes then adds the whole
-// 64-byte gradient record of the Gaussian: one contiguous atomic segment per (Gaussian, wave), the shape
-// MI355X's memory-side float atomics run fastest on.  The fold is skipped for the whole wave when a
-// ballot shows no lane received a contribution.
+// reference's ~10 atomics per pair).  They are reduced over the wave's 64 pixels first, in two ways:
+//   * the C feature slots (+ depth) are rank one in (entry, pixel) -- weight x upstream pixel gradient -- and go
+//     through the MATRIX CORES sixteen entries at a time (RankOneFold below: exact-fp32 16x16x4 MFMAs);
+//   * the six geometry slots (mean2D x2, conic x3, opacity) are folded on the VALU with a transposed butterfly
+//         v_permlane32_swap (xor 32) -> v_permlane16_swap (xor 16) -> DPP row_ror:8 -> quad_perm x2 -> row_half_mirror
+//     (wave_fold8: ~17 VALU for 8 slots; round 1 folded all 16 slots this way, ~35 VALU) so that lane 8*s ends up
+//     with the wave total of slot s.
+// Atomics: one instruction per (Gaussian, wave) for the geometry segment, one per FOUR entries for the feature
+// rows, into the fp64 gradient record.  An entry is skipped for the whole wave when a ballot shows no lane
+// received a contribution.
 //
 // `geom_channels` (<= C): only feature channels [0, geom_channels) plus depth and alpha feed dL/dalpha,
 // i.e. the geometry / opacity gradients; channels beyond it only receive their own dL/dfeature.  This is
@@ -26,6 +27,74 @@ namespace ogs {
 namespace {
 
 constexpr float kAlphaMin = 1.0f / 255.0f;
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+// ---- rank-one part of the reduction on the matrix cores ----------------------------------------------------------
+// The feature (and depth) slots of the gradient record are rank one in (entry, pixel): dL/dfeature_c(i) =
+// sum over the quadrant's pixels p of w_i(p) * g_c(p), with w_i(p) = alpha_i(p) * T_i(p) the blend weight and g_c(p)
+// the upstream pixel gradient, which does not depend on the entry.  For a batch of 16 accepted entries that is the
+// matrix product  D[16 entries, channels] = W[16, 64 pixels] x G[64, channels]  -- sixteen exact-fp32
+// v_mfma_f32_16x16x4_f32 (K = 4 pixels each) instead of 16 butterfly folds of up to ten slots: per entry ONE
+// ds_write (its weights, one per lane), one ds_read + one MFMA of the batch's sixteen, and a quarter of an atomic
+// instruction (one instruction adds four entries' channel rows).  The VALU fold is left with the six geometry slots.
+//   A operand of MFMA j, lane l: W[entry l % 16][pixel 4 j + l / 16]   (read back transposed from LDS)
+//   B operand of MFMA j, lane l: G[pixel 4 j + l / 16][channel l % 16] (loop invariant: 16 registers per lane)
+//   D, lane l, register r:       entry 4 (l / 16) + r, channel l % 16
+// LDS: 16 x 66 floats per wave (row stride 66 words: the transposed read is bank-conflict free) + 16 Gaussian ids.
+constexpr int kFoldRows = 16;
+constexpr int kFoldStride = 66;
+struct WaveFoldLds {
+    float w[kFoldRows * kFoldStride];
+    uint32_t gid[kFoldRows];
+};
+
+template <int NCH, int SLOT0, int GS, typename ACC>
+struct RankOneFold {
+    float* w;
+    uint32_t* gid;
+    float B[16];
+    int cnt;        // wave-uniform: entries staged
+
+    // gmap(n, inside, pix): upstream gradient of channel n at a pixel of image `img`
+    template <typename F>
+    __device__ __forceinline__ void init(WaveFoldLds* lds, int lane, int tx, int ty, int wave, int W, int H, F gmap) {
+        w = lds->w;
+        gid = lds->gid;
+        cnt = 0;
+        const int n = lane & 15, kq = lane >> 4;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int q = 4 * j + kq;                                   // pixel of the 8x8 quadrant, lane order
+            const int px = tx * kTile + (wave & 1) * 8 + (q & 7);
+            const int py = ty * kTile + (wave >> 1) * 8 + (q >> 3);
+            const bool in = px < W && py < H && n < NCH;
+            B[j] = in ? gmap(n < NCH ? n : 0, (size_t)py * W + px) : 0.f;
+        }
+    }
+    __device__ __forceinline__ void flush(ACC* __restrict__ grad_rec, int lane) {
+        const int m = lane & 15, kq = lane >> 4;
+        floatx4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float a = m < cnt ? w[m * kFoldStride + 4 * j + kq] : 0.f;
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, B[j], d, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = 4 * kq + r;
+            if (e < cnt && m < NCH) atomicAdd(grad_rec + (size_t)gid[e] * GS + SLOT0 + m, (ACC)d[r]);
+        }
+        cnt = 0;
+    }
+    // one accepted entry: this lane's weight, the entry's Gaussian (wave-uniform)
+    __device__ __forceinline__ void push(float wl, uint32_t g, ACC* __restrict__ grad_rec, int lane) {
+        w[cnt * kFoldStride + lane] = wl;
+        if (lane == 0) gid[cnt] = g;
+        ++cnt;
+        if (cnt == kFoldRows) flush(grad_rec, lane);
+    }
+};
+
 __device__ __forceinline__ int wave_max_i32(int v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, kWave));
@@ -45,6 +114,8 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     constexpr int RS = stream_vec4(C) * 4;
     constexpr int GS = grad_stride(C);
     static_assert(C + 7 <= 16, "gradient record must fit 16 slots");
+    constexpr int NCH = C + (DEPTH ? 1 : 0);     // rank-one slots: features (+ depth) -> matrix cores
+    __shared__ WaveFoldLds s_fold[kBlock / kWave];
 
     const int tile = blockIdx.x;                // virtual tile (grouped pass): image * tiles + tile in the image
     const int img = tile / tiles, timg = tile - img * tiles;
@@ -57,6 +128,8 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     const size_t plane = (size_t)W * H;
     const size_t pix = (size_t)img * plane + (size_t)py * W + px;       // pixel of image `img` in [G,1,H,W] maps
     dL_dcolor += (size_t)img * (C - 1) * plane;                         // + pix: image stride of [G,C,H,W] is C planes
+    const float* __restrict__ dcol_img = dL_dcolor + (size_t)img * plane;   // image `img`, indexed by py * W + px
+    const float* __restrict__ ddep_img = DEPTH ? dL_ddepth + (size_t)img * plane : nullptr;
 
     const uint2 range = ranges[tile];
     const int last_contrib = inside ? (int)n_contrib[pix] : 0;
@@ -80,14 +153,12 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     }
     const float gd = (DEPTH && inside) ? dL_ddepth[pix] : 0.f;
     const float ga = (inside && dL_dalpha_map) ? dL_dalpha_map[pix] : 0.f;
-    // (dL/dpixel_0 .. dL/dpixel_{C-1}, dL/ddepth) as register pairs for v_pk_mul_f32
-    constexpr int NP = (C + 2) / 2;
-    v2f gp[NP];
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-        gp[k].x = 2 * k < C ? g[2 * k < C ? 2 * k : 0] : (2 * k == C ? gd : 0.f);
-        gp[k].y = 2 * k + 1 < C ? g[2 * k + 1 < C ? 2 * k + 1 : 0] : (2 * k + 1 == C ? gd : 0.f);
-    }
+    // dL/dfeature_c and dL/ddepth of an entry are w * g(pixel): rank one -> RankOneFold (matrix cores); the six
+    // geometry slots (mean2D x2, conic x3, opacity) stay on the VALU butterfly, now 8 slots wide
+    RankOneFold<NCH, 0, GS, ACC> fold;
+    fold.init(&s_fold[wave], lane, tx, ty, wave, W, H, [&](int n, size_t p) {
+        return (DEPTH && n == C) ? ddep_img[p] : dcol_img[(size_t)(n < C ? n : 0) * plane + p];
+    });
     float R[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) R[c] = 0.f;
@@ -104,7 +175,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
         // |power + h| <= h decides thr <= power <= 0
         const float fxe = idx < last_contrib ? fx : kFar;
         const float dx = cur[0] - fxe, dy = cur[1] - fy;
-        const float power = a2 * dx * dx + c2 * dy * dy + b2 * dx * dy;
+        const float power = blend_power(a2, b2, c2, dx, dy);
         const bool cand = fabsf(power + cur[5]) <= cur[5];
         // All 64 lanes run the same straight-line arithmetic (with the per-quadrant streams nearly every entry
         // has candidates, so a divergent region would save no issue slots, only cost exec-mask SALU ops and a
@@ -117,23 +188,14 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
         if (__ballot(act) != 0ull) {
             const float al = act ? alpha : 0.f;
             const float G = act ? Graw : 0.f;
-            float v[16];
+            float v[8];
             // 1-ulp hardware reciprocal: the correctly rounded 1/x is a ~10-instruction sequence per entry, and the
             // T recursion is dominated by the rounding of the multiply anyway
             const float inv = __builtin_amdgcn_rcpf(1.0f - al);
             T = T * inv;
             const float w = al * T;
             float dL_dalpha = 0.f;
-            // dL/dfeature_c = w * dL/dpixel_c (and the depth slot): packed fp32 multiplies, two slots per VALU op
-            {
-                const v2f w2 = {w, w};
-#pragma unroll
-                for (int k = 0; k < NP; ++k) {
-                    const v2f t = gp[k] * w2;
-                    v[2 * k] = t.x;
-                    if (2 * k + 1 <= C) v[2 * k + 1] = t.y;
-                }
-            }
+            fold.push(w, __float_as_uint(cur[7]), grad_rec, lane);     // features (+ depth): matrix cores
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 if (c < GC) {
@@ -160,21 +222,20 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
             const float q = opac * sG;
             const float ppx = (2.f * a2) * dx + b2 * dy;
             const float ppy = (2.f * c2) * dy + b2 * dx;
-            v[C + 1] = (q * halfW) * ppx;
-            v[C + 2] = (q * halfH) * ppy;
+            v[0] = (q * halfW) * ppx;
+            v[1] = (q * halfH) * ppy;
             const float hq = -0.5f * q;
             const float hqdx = hq * dx;
-            v[C + 3] = hqdx * dx;
-            v[C + 4] = hqdx * dy;
-            v[C + 5] = (hq * dy) * dy;
-            v[C + 6] = sG;
-#pragma unroll
-            for (int k = C + 7; k < 16; ++k) v[k] = 0.f;
-            const float y = wave_fold16(v);
-            const int slot = lane >> 2;
-            if ((lane & 3) == 0 && slot < C + 7) {
+            v[2] = hqdx * dx;
+            v[3] = hqdx * dy;
+            v[4] = (hq * dy) * dy;
+            v[5] = sG;
+            v[6] = 0.f; v[7] = 0.f;
+            const float y = wave_fold8(v);
+            const int slot = lane >> 3;
+            if ((lane & 7) == 0 && slot < 6) {
                 const uint32_t gid = __float_as_uint(cur[7]);
-                atomicAdd(grad_rec + (size_t)gid * GS + slot, (ACC)y);
+                atomicAdd(grad_rec + (size_t)gid * GS + (C + 1) + slot, (ACC)y);
             }
         }
     };
@@ -193,6 +254,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
         i1 = n3; i2 = n4;
         q -= 2;
     }
+    if (fold.cnt > 0) fold.flush(grad_rec, lane);
 }
 
 // Features-only backward (SURVEY.md section 0 item 6, section 8 f1 "skip geometry grads when detached"): from
@@ -200,8 +262,8 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
 // owes is dL/dfeature_c = sum over pixels of (alpha * T) * dL/dpixel_c.  No alpha-gradient recursion, no geometry
 // partials, no T recovery by division: the quadrant stream is walked FRONT-TO-BACK with the forward's own
 // recurrence (w = alpha * T, T *= 1 - alpha), so the weights are bit-identical to the forward pass.  Only channels
-// [F0, C) are produced (F0 = 3 in a fused pass whose channels 0..2 come from the -- detached -- SH colours); NS =
-// C - F0 <= 8 slots are folded with the 8-slot butterfly, 9 slots with the 16-slot one.
+// [F0, C) are produced (F0 = 3 in a fused pass whose channels 0..2 come from the -- detached -- SH colours), and
+// all of them through the matrix cores: no butterfly fold at all.
 template <int C, int F0, typename ACC>
 __global__ __launch_bounds__(kBlock) void blend_backward_feat_kernel(
     const uint2* __restrict__ ranges, const float* __restrict__ stream, const uint32_t* __restrict__ quad_list, int W,
@@ -210,8 +272,8 @@ __global__ __launch_bounds__(kBlock) void blend_backward_feat_kernel(
     constexpr int RS = stream_vec4(C) * 4;
     constexpr int GS = grad_stride(C);
     constexpr int NS = C - F0;
-    constexpr bool kFold8 = NS <= 8;
     static_assert(NS >= 1 && NS <= 16, "feature slots");
+    __shared__ WaveFoldLds s_fold[kBlock / kWave];
 
     const int tile = blockIdx.x;
     const int img = tile / tiles, timg = tile - img * tiles;
@@ -223,7 +285,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_feat_kernel(
     const float fx = (float)px, fy = (float)py;
     const size_t plane = (size_t)W * H;
     const size_t pix = (size_t)img * plane + (size_t)py * W + px;
-    dL_dcolor += (size_t)img * (C - 1) * plane;
+    dL_dcolor += (size_t)img * C * plane;                               // image `img` of [G,C,H,W]
 
     const uint2 range = ranges[tile];
     const int last_contrib = inside ? (int)n_contrib[pix] : 0;
@@ -235,20 +297,17 @@ __global__ __launch_bounds__(kBlock) void blend_backward_feat_kernel(
     const uint32_t lim = n_tile > 0 ? (uint32_t)n_tile - 1u : 0u;
     auto rec_at = [&](uint32_t i) { return tb + (size_t)(min(i, lim) * (uint32_t)RS); };
 
-    constexpr int NP = (NS + 1) / 2;
-    v2f gp[NP];
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-        gp[k].x = inside ? dL_dcolor[(size_t)(F0 + 2 * k) * plane + pix] : 0.f;
-        gp[k].y = (2 * k + 1 < NS && inside) ? dL_dcolor[(size_t)(F0 + (2 * k + 1 < NS ? 2 * k + 1 : 0)) * plane + pix] : 0.f;
-    }
+    // the whole reduction is rank one: every slot goes through the matrix cores (RankOneFold above)
+    RankOneFold<NS, F0, GS, ACC> fold;
+    fold.init(&s_fold[wave], lane, tx, ty, wave, W, H,
+              [&](int n, size_t p) { return dL_dcolor[(size_t)(F0 + n) * plane + p]; });
     float T = 1.0f;
 
     auto consume = [&](const StreamRec<C>& rec_j, int idx) {
         const f8 cur = rec_j.g;
         const float fxe = idx < last_contrib ? fx : kFar;           // pixels past their last contributor are parked
         const float dx = cur[0] - fxe, dy = cur[1] - fy;
-        const float power = cur[2] * dx * dx + cur[4] * dy * dy + cur[3] * dx * dy;
+        const float power = blend_power(cur[2], cur[3], cur[4], dx, dy);
         const bool cand = fabsf(power + cur[5]) <= cur[5];
         const float alpha = fminf(0.99f, cur[6] * __expf(power));
         const bool act = cand && alpha >= kAlphaMin;
@@ -256,32 +315,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_feat_kernel(
             const float al = act ? alpha : 0.f;
             const float w = al * T;
             T = T * (1.0f - al);
-            const v2f w2 = {w, w};
-            float v[kFold8 ? 8 : 16];
-#pragma unroll
-            for (int k = 0; k < (kFold8 ? 8 : 16); ++k) v[k] = 0.f;
-#pragma unroll
-            for (int k = 0; k < NP; ++k) {
-                const v2f t = gp[k] * w2;
-                v[2 * k] = t.x;
-                if (2 * k + 1 < NS) v[2 * k + 1] = t.y;
-            }
-            float y;
-            int slot;
-            bool writer;
-            if constexpr (kFold8) {
-                y = wave_fold8(v);
-                slot = lane >> 3;
-                writer = (lane & 7) == 0;
-            } else {
-                y = wave_fold16(v);
-                slot = lane >> 2;
-                writer = (lane & 3) == 0;
-            }
-            if (writer && slot < NS) {
-                const uint32_t gid = __float_as_uint(cur[7]);
-                atomicAdd(grad_rec + (size_t)gid * GS + F0 + slot, (ACC)y);
-            }
+            fold.push(w, __float_as_uint(cur[7]), grad_rec, lane);
         }
     };
     // front-to-back over the quadrant's index stream, batches of two records with pinned scalar waits (blend_fwd.hip)
@@ -303,6 +337,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_feat_kernel(
         if (j + 3 < hi) consume(b1, j + 3);
         i2 = n6; i3 = n7; i4 = n8; i5 = n9;
     }
+    if (fold.cnt > 0) fold.flush(grad_rec, lane);
 }
 
 // self-test hook for the fold: in [64 lanes][16 slots] -> out[lane] = value left in each lane

@@ -205,7 +205,7 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
     auto consume = [&](const StreamRec<C>& rec_j, int j) {
         const f8 cur = rec_j.g;
         const float dx = cur[0] - fxe, dy = cur[1] - fy;
-        const float power = cur[2] * dx * dx + cur[4] * dy * dy + cur[3] * dx * dy;
+        const float power = blend_power(cur[2], cur[3], cur[4], dx, dy);
         const bool cand = fabsf(power + cur[5]) <= cur[5];
         if (__ballot(cand) != 0ull) {
             bool stop = false;
@@ -217,7 +217,8 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
                 const float w = stop ? 0.f : alpha * T;
                 const v2f w2 = {w, w};
 #pragma unroll
-                for (int k = 0; k < NPF; ++k) accp[k] += (v2f){rec_j.feat(2 * k), rec_j.feat(2 * k + 1)} * w2;
+                for (int k = 0; k < NPF; ++k)       // explicit FMA (the tiny pass reproduces these bits)
+                    accp[k] = __builtin_elementwise_fma((v2f){rec_j.feat(2 * k), rec_j.feat(2 * k + 1)}, w2, accp[k]);
                 wacc += w;
                 T = stop ? T : test_T;
                 last = w > 0.f ? (uint32_t)j + 1u : last;
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(kBlock) void tiny_blend_kernel(int P, const uint32_
         if (__ballot(!done) == 0ull) break;
         const float* r = s_rec + j * RS;                          // wave-uniform LDS address: broadcast reads
         const float dx = r[0] - fx, dy = r[1] - fy;
-        const float power = r[2] * dx * dx + r[4] * dy * dy + r[3] * dx * dy;
+        const float power = blend_power(r[2], r[3], r[4], dx, dy);
         const bool cand = !done && fabsf(power + r[5]) <= r[5];
         if (cand) {
             float alpha = fminf(0.99f, r[6] * __expf(power));

@@ -12,6 +12,8 @@
 // second kernel sums the tables in fixed order and applies the reference's count/centre bookkeeping.
 // Algorithmic traffic per iteration: N*4*d bytes read (+ N*8 for the final id write).
 // Shapes outside the MFMA tiling (k > 256 or d > 15) use the LDS-accumulator fallback kernel.
+#include <stdlib.h>
+
 #include "ogs_common.h"
 #include "../../include/ogs_kmeans.h"
 
@@ -100,12 +102,12 @@ __device__ __forceinline__ void nearest_centre2(const float* __restrict__ rows, 
 
 // ---- MFMA path: CB blocks of 16 clusters (k <= 16*CB), d <= 15 ---------------------------------------------------
 // ACCUM: Lloyd iteration (partials only); otherwise final re-assignment (ids only)
-template <int CB, bool ACCUM, int DT>
+template <int CB, bool ACCUM, int DT, int PPL>
 __global__ __launch_bounds__(kBlock) void kmeans_mfma_pass_kernel(const float* __restrict__ feat, int64_t N, int d,
                                                                   const float* __restrict__ centers, int k,
                                                                   int k_active, int64_t* __restrict__ ids_out,
                                                                   int64_t id_offset, float* __restrict__ partials) {
-    constexpr int PPL = DT > 0 ? 2 : 1;                 // points per lane
+    static_assert(PPL == 1 || (PPL == 2 && DT > 0), "two points per lane need a compile-time width");
     constexpr int ROWS = kBlock * PPL;                  // rows staged per trip
     extern __shared__ float smem[];
     float* cs = smem;                                   // [k*d] centres
@@ -301,6 +303,15 @@ __global__ __launch_bounds__(kBlock) void kmeans_gather_kernel(const float* __re
     out[i] = centers[ids[row] * vec_dim + col];
 }
 
+// tuning knobs (A/B timing only): OGS_KM_PPL=1 -> one point per lane; OGS_KM_BLOCKS=n -> workgroups per pass
+inline int km_ppl() {
+    static const int v = [] { const char* e = getenv("OGS_KM_PPL"); return (e && atoi(e) == 1) ? 1 : 2; }();
+    return v;
+}
+inline int km_max_blocks() {
+    static const int v = [] { const char* e = getenv("OGS_KM_BLOCKS"); const int n = e ? atoi(e) : 0; return n > 0 ? n : kMaxBlocks; }();
+    return v;
+}
 int check_dims(int64_t N, int d, int k) {
     if (N < 0 || d < 1 || d > kMaxD || k < 1 || (int64_t)k * (d + 1) > OGS_KMEANS_MAX_ACC) {
         set_error("kmeans: unsupported sizes N=%lld d=%d k=%d (d <= %d, k*(d+1) <= %d)", (long long)N, d, k, kMaxD,
@@ -312,7 +323,8 @@ int check_dims(int64_t N, int d, int k) {
 
 int pass_blocks(int64_t N) {      // upper bound over both trip sizes (tmp sizing); workgroups grid-stride anyway
     const int64_t nblk = (N + kBlock - 1) / kBlock;
-    return (int)(nblk < kMaxBlocks ? (nblk > 0 ? nblk : 1) : kMaxBlocks);
+    const int mb = km_max_blocks();
+    return (int)(nblk < mb ? (nblk > 0 ? nblk : 1) : mb);
 }
 
 int cluster_blocks(int d, int k) {       // 0: MFMA tiling not applicable
@@ -320,7 +332,7 @@ int cluster_blocks(int d, int k) {       // 0: MFMA tiling not applicable
     return k <= 16 ? 1 : (k <= 64 ? 4 : 16);
 }
 
-inline int rows_per_trip(int d) { return (d == 6 || d == 9) ? 2 * kBlock : kBlock; }   // compile-time widths: 2 points per lane
+inline int rows_per_trip(int d) { return ((d == 6 || d == 9) && km_ppl() == 2) ? 2 * kBlock : kBlock; }   // compile-time widths: 2 points per lane
 size_t mfma_lds(int d, int k, int CB, bool accum) {
     const size_t rows = (size_t)rows_per_trip(d);
     // staged rows + ids; the epilogue's per-wave tables reuse the rows region
@@ -341,17 +353,27 @@ int allow_lds(K kernel, size_t bytes) {
     return OGS_OK;
 }
 
-template <int CB, bool ACCUM, int DT>
-int launch_mfma_d(int nb, hipStream_t s, const float* feat, int64_t N, int d, const float* centers, int k, int k_active,
+template <int CB, bool ACCUM, int DT, int PPL>
+int launch_mfma_p(int nb, hipStream_t s, const float* feat, int64_t N, int d, const float* centers, int k, int k_active,
                   int64_t* ids_out, int64_t id_offset, float* partials) {
     const size_t lds = mfma_lds(d, k, CB, ACCUM);
-    int rc = allow_lds(kmeans_mfma_pass_kernel<CB, ACCUM, DT>, lds);
+    int rc = allow_lds(kmeans_mfma_pass_kernel<CB, ACCUM, DT, PPL>, lds);
     if (rc != OGS_OK) return rc;
     OGS_LAUNCH_NAMED(ACCUM ? "kmeans_mfma_pass_kernel<accum>" : "kmeans_mfma_pass_kernel<assign>",
-                     (kmeans_mfma_pass_kernel<CB, ACCUM, DT>), dim3(nb), dim3(kBlock), lds, s, feat, N, d, centers, k,
+                     (kmeans_mfma_pass_kernel<CB, ACCUM, DT, PPL>), dim3(nb), dim3(kBlock), lds, s, feat, N, d, centers, k,
                      k_active, ids_out, id_offset, partials);
     OGS_LAUNCH_CHECK(0, s);
     return OGS_OK;
+}
+
+template <int CB, bool ACCUM, int DT>
+int launch_mfma_d(int nb, hipStream_t s, const float* feat, int64_t N, int d, const float* centers, int k, int k_active,
+                  int64_t* ids_out, int64_t id_offset, float* partials) {
+    if constexpr (DT > 0) {
+        if (km_ppl() == 2)
+            return launch_mfma_p<CB, ACCUM, DT, 2>(nb, s, feat, N, d, centers, k, k_active, ids_out, id_offset, partials);
+    }
+    return launch_mfma_p<CB, ACCUM, DT, 1>(nb, s, feat, N, d, centers, k, k_active, ids_out, id_offset, partials);
 }
 
 template <int CB, bool ACCUM>

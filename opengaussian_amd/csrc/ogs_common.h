@@ -281,6 +281,16 @@ int launch_mark_visible(int P, const float* means3D, const float* viewmatrix, ui
 int launch_export_keys(const uint2* ranges, int tiles, const uint32_t* point_list, const float4* rec, int recv4,
                        uint64_t* keys_out, hipStream_t s);
 
+// ---- blend arithmetic shared by every kernel that evaluates a Gaussian at a pixel ----------------------------------
+// power = a2*dx^2 + b2*dx*dy + c2*dy^2 (a2 = -A/2, b2 = -B, c2 = -C/2) in ONE fixed operation order with explicit
+// FMAs.  The forward, both backward variants and the tiny pass must reproduce the same bits: a pixel's skip
+// decisions (alpha >= 1/255, T < 1e-4) are re-taken by the backward pass from the recomputed alpha, and left to the
+// compiler the contraction of this expression differed from kernel to kernel (SGPR vs LDS operands).
+__device__ __forceinline__ float blend_power(float a2, float b2, float c2, float dx, float dy) {
+    const float u = fmaf(b2, dy, a2 * dx);         // a2*dx + b2*dy
+    return fmaf(c2 * dy, dy, u * dx);              // (a2*dx + b2*dy)*dx + c2*dy^2
+}
+
 // ---- tiny device helpers ------------------------------------------------------------------------
 // s_waitcnt lgkmcnt(0) (vmcnt / expcnt untouched), pinned in place: nothing is scheduled across it
 __device__ __forceinline__ void wait_scalar_loads() {

@@ -118,6 +118,43 @@ def test_render_matches_reference_pass_structure(gpu_device, seed, expect_rescal
     assert float((ga - gb).abs().max()) / float(gb.abs().max()) < 1e-3
 
 
+def test_render_stage1_detached_geometry_runs_features_only_backward(gpu_device):
+    """train.py:431-436: from stage 1 on xyz / SH / opacity / scaling / rotation are detached and only `_ins_feat`
+    trains.  render() then stops asking for viewspace_points.grad (consumed by densification only, train.py:594-598)
+    and the rasterizer runs its features-only backward: dL/d ins_feat must equal what the all-gradients graph gives,
+    nothing else receives a gradient; viewspace_grad=True restores the reference's means2D gradient."""
+    from opengaussian_amd.renderer import render
+    dev = gpu_device
+    W, H, f = 160, 96, 120.0
+    sc, cam = helpers.tiny_scene(2500, W, H, f, seed=21)
+    cam = cam.to(dev)
+    pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=False)
+    bg = torch.tensor([0.2, 0.1, 0.3], device=dev)
+    g = torch.Generator().manual_seed(4)
+    gF, gR = torch.randn(6, H, W, generator=g).to(dev), torch.randn(3, H, W, generator=g).to(dev)
+
+    def run(detach, **kw):
+        pc = FakeGaussians(sc, dev)
+        if detach:                                             # what train.py:431-436 does to the model
+            for name in ("_xyz", "_scaling", "_rotation", "_opacity", "_features"):
+                setattr(pc, name, getattr(pc, name).detach())
+        torch.manual_seed(0)                                   # prob <= 0.5: no rescale -> the fused 9-channel pass
+        out = render(cam, pc, pipe, bg, iteration=1, **kw)
+        ((out["ins_feat"] * gF).sum() + (out["render"] * gR).sum()).backward()
+        return out, pc
+
+    out_d, pc_d = run(True)
+    assert out_d["viewspace_points"].grad is None
+    out_f, pc_f = run(False)
+    assert out_f["viewspace_points"].grad is not None
+    assert torch.equal(out_d["ins_feat"], out_f["ins_feat"]) and torch.equal(out_d["render"], out_f["render"])
+    scale = float(pc_f._ins_feat.grad.abs().max())
+    assert float((pc_d._ins_feat.grad - pc_f._ins_feat.grad).abs().max()) / scale < 2e-5
+    out_v, pc_v = run(True, viewspace_grad=True)
+    torch.testing.assert_close(out_v["viewspace_points"].grad, out_f["viewspace_points"].grad, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(pc_v._ins_feat.grad, pc_f._ins_feat.grad, rtol=1e-5, atol=1e-7)
+
+
 def test_render_post_process_and_leaf_path(gpu_device):
     from opengaussian_amd.renderer import render
     dev = gpu_device
