@@ -111,7 +111,7 @@ __global__ __launch_bounds__(kBlock) void kmeans_mfma_pass_kernel(const float* _
     constexpr int ROWS = kBlock * PPL;                  // rows staged per trip
     extern __shared__ float smem[];
     float* cs = smem;                                   // [k*d] centres
-    float* rows = cs + k * d;                           // [ROWS*d] staged rows
+    float* rows = cs + ((k * d + 3) & ~3);              // [ROWS*d] staged rows, 16-byte aligned (float4 stores)
     int* ids_s = reinterpret_cast<int*>(rows + ROWS * d);     // [ROWS] ids of the staged rows (-1: no row)
     float* wtab = rows;                                 // [4][CB*16][16] per-wave tables: epilogue only, reuses `rows`
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -127,7 +127,31 @@ __global__ __launch_bounds__(kBlock) void kmeans_mfma_pass_kernel(const float* _
         const int64_t row0 = blk * ROWS;
         const int nrows = (int)min((int64_t)ROWS, N - row0);
         const float* src = feat + row0 * d;
-        for (int i = tid; i < nrows * d; i += kBlock) rows[i] = src[i];
+        if constexpr (DT > 0 && (ROWS * DT) % 4 == 0) {
+            // Full trips: every thread issues ALL its 16-byte loads before the first LDS store.  (The plain
+            // `rows[i] = src[i]` loop ran one dependent load -> store round trip per iteration: 34 sequential HBM
+            // latencies per workgroup and pass -- the pass was bound by that, not by the distance loop: halving the
+            // loop's VALU work with packed math changed nothing until the staging was fixed.)
+            constexpr int NV4 = ROWS * DT / 4;                       // float4s per trip (a trip starts 16-byte aligned)
+            constexpr int ITER = (NV4 + kBlock - 1) / kBlock;
+            if (nrows == ROWS && (reinterpret_cast<uintptr_t>(src) & 15u) == 0) {
+                float4 buf[ITER];
+#pragma unroll
+                for (int it = 0; it < ITER; ++it) {
+                    const int idx = tid + it * kBlock;
+                    if (idx < NV4) buf[it] = reinterpret_cast<const float4*>(src)[idx];
+                }
+#pragma unroll
+                for (int it = 0; it < ITER; ++it) {
+                    const int idx = tid + it * kBlock;
+                    if (idx < NV4) reinterpret_cast<float4*>(rows)[idx] = buf[it];
+                }
+            } else {
+                for (int i = tid; i < nrows * d; i += kBlock) rows[i] = src[i];
+            }
+        } else {
+            for (int i = tid; i < nrows * d; i += kBlock) rows[i] = src[i];
+        }
         __syncthreads();
         if constexpr (PPL == 2) {
             // rows tid and tid + 256: both halves of the register pairs always hold a valid row (a missing second
@@ -338,7 +362,7 @@ size_t mfma_lds(int d, int k, int CB, bool accum) {
     // staged rows + ids; the epilogue's per-wave tables reuse the rows region
     const size_t body = rows * d + rows;
     const size_t wtab = accum ? (size_t)4 * CB * 16 * 16 : 0;
-    return sizeof(float) * ((size_t)k * d + (body > wtab ? body : wtab));
+    return sizeof(float) * ((((size_t)k * d + 3) & ~(size_t)3) + (body > wtab ? body : wtab));
 }
 size_t fallback_lds(int d, int k, bool accum) {
     return sizeof(float) * ((size_t)k * d + (size_t)kBlock * d + (accum ? (size_t)k * (d + 1) : 0));

@@ -301,14 +301,18 @@ class _RasterizeGaussians(torch.autograd.Function):
             return (None,) * 13
         lib = _lib.lib()
         H, W = int(rs.image_height), int(rs.image_width)
+        scratch = None
         if ctx.tiny:
             # a tiny pass keeps nothing: re-render through the streaming path (scratch outputs) to obtain the binning
             # and blend state the backward kernels read.  Rare: the refiner's footprint renders never call backward.
             (m3, shs, cols, opac, scl, rot, cov, bg, view, proj, campos, radii, alpha) = ctx.saved_tensors
             dev = m3.device
             e = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
-            a = _fwd_args(rs, P, Cn, m3, shs, cols, opac, scl, rot, cov, bg, view, proj, campos, e(Cn, H, W), e(1, H, W),
-                          e(1, H, W), torch.empty(P, dtype=torch.int32, device=dev), None, 1)
+            # scratch outputs: held in `scratch` until the re-render has been enqueued AND everything else of this
+            # backward has been allocated -- `a` only carries raw pointers, a tensor freed here would be handed out
+            # again by the caching allocator while the kernels still write through the old pointer
+            scratch = (e(Cn, H, W), e(1, H, W), e(1, H, W), torch.empty(P, dtype=torch.int32, device=dev))
+            a = _fwd_args(rs, P, Cn, m3, shs, cols, opac, scl, rot, cov, bg, view, proj, campos, *scratch, None, 1)
             geom, image, point_list, sorted_rec, quad_list, D = _streaming_render(a, dev, lib, False)
             ctx.num_rendered = D
             PASS_STATS["tiny_rerendered_for_backward"] += 1
@@ -358,6 +362,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         b.dL_dcov3D, b.dL_dsh, b.dL_dscales, b.dL_drotations = ptr(g_cov), ptr(g_sh), ptr(g_scl), ptr(g_rot)
         b.dL_dsh_rgb = ptr(g_sh_rgb)
         check(lib.ogs_raster_backward(C.byref(b), _stream()), "ogs_raster_backward")
+        scratch = None          # (tiny pass re-render) stream-ordered: safe to recycle once the launches are queued
         if _DEBUG_KEEP_BWD_TMP is not None:
             _DEBUG_KEEP_BWD_TMP.append(bwd_tmp)
         if sink is not None:
