@@ -110,7 +110,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     const uint2* __restrict__ ranges, const float* __restrict__ stream, const uint32_t* __restrict__ quad_list, int W,
     int H, int gx, int tiles, const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha_map,
-    ACC* __restrict__ grad_rec) {
+    ACC* __restrict__ grad_rec, int pf_lines) {
     constexpr int RS = stream_vec4(C) * 4;
     constexpr int GS = grad_stride(C);
     static_assert(C + 7 <= 16, "gradient record must fit 16 slots");
@@ -141,6 +141,8 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     const uint32_t* __restrict__ qi = quad_list + ((size_t)range.x * 4 + (size_t)wave * n_tile);     // quadrant's indices
     const uint32_t lim = n_tile > 0 ? (uint32_t)n_tile - 1u : 0u;
     auto rec_at = [&](uint32_t i) { return tb + (size_t)(min(i, lim) * (uint32_t)RS); };
+    RecordPrefetch pf;
+    pf.issue(tb, n_tile, RS, tid, pf_lines);
 
     const float T_final = inside ? final_T[pix] : 0.f;      // the forward's own value (ImageState::final_T)
     float T = T_final;
@@ -255,6 +257,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
         q -= 2;
     }
     if (fold.cnt > 0) fold.flush(grad_rec, lane);
+    pf.retire(reinterpret_cast<uint32_t*>(grad_rec), W);
 }
 
 // Features-only backward (SURVEY.md section 0 item 6, section 8 f1 "skip geometry grads when detached"): from
@@ -268,7 +271,7 @@ template <int C, int F0, typename ACC>
 __global__ __launch_bounds__(kBlock) void blend_backward_feat_kernel(
     const uint2* __restrict__ ranges, const float* __restrict__ stream, const uint32_t* __restrict__ quad_list, int W,
     int H, int gx, int tiles, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
-    ACC* __restrict__ grad_rec) {
+    ACC* __restrict__ grad_rec, int pf_lines) {
     constexpr int RS = stream_vec4(C) * 4;
     constexpr int GS = grad_stride(C);
     constexpr int NS = C - F0;
@@ -296,6 +299,8 @@ __global__ __launch_bounds__(kBlock) void blend_backward_feat_kernel(
     const uint32_t* __restrict__ qi = quad_list + ((size_t)range.x * 4 + (size_t)wave * n_tile);
     const uint32_t lim = n_tile > 0 ? (uint32_t)n_tile - 1u : 0u;
     auto rec_at = [&](uint32_t i) { return tb + (size_t)(min(i, lim) * (uint32_t)RS); };
+    RecordPrefetch pf;
+    pf.issue(tb, n_tile, RS, tid, pf_lines);
 
     // the whole reduction is rank one: every slot goes through the matrix cores (RankOneFold above)
     RankOneFold<NS, F0, GS, ACC> fold;
@@ -338,6 +343,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_feat_kernel(
         i2 = n6; i3 = n7; i4 = n8; i5 = n9;
     }
     if (fold.cnt > 0) fold.flush(grad_rec, lane);
+    pf.retire(reinterpret_cast<uint32_t*>(grad_rec), W);
 }
 
 // self-test hook for the fold: in [64 lanes][16 slots] -> out[lane] = value left in each lane
@@ -370,7 +376,7 @@ int launch_c(const OgsRasterBwdArgs& a, const ImageState& is, void* grad_rec_, h
 #define OGS_BWD_FEAT(F0V)                                                                                             \
     OGS_LAUNCH_NAMED(chan_name<C>(kFeatNames), (blend_backward_feat_kernel<C, F0V, ACC>), dim3(vtiles), dim3(kBlock), 0, \
                      s, (const uint2*)is.ranges, stream, quads, a.W, a.H, gx, gx * gy, (const uint32_t*)is.n_contrib,    \
-                     a.dL_dcolor, grad_rec)
+                     a.dL_dcolor, grad_rec, blend_prefetch_lines())
         if constexpr (C > 3) {
             if (a.shs != nullptr) OGS_BWD_FEAT(3); else OGS_BWD_FEAT(0);
         } else {
@@ -383,7 +389,7 @@ int launch_c(const OgsRasterBwdArgs& a, const ImageState& is, void* grad_rec_, h
 #define OGS_BWD_LAUNCH(GCV, DEPTHV)                                                                                  \
     OGS_LAUNCH_NAMED(chan_name<C>(kNames), (blend_backward_kernel<C, GCV, DEPTHV, ACC>), dim3(vtiles), dim3(kBlock), 0, s, \
                      (const uint2*)is.ranges, stream, quads, a.W, a.H, gx, gx * gy, a.bg, (const float*)is.final_T,                  \
-                     (const uint32_t*)is.n_contrib, a.dL_dcolor, a.dL_ddepth, a.dL_dalpha, grad_rec)
+                     (const uint32_t*)is.n_contrib, a.dL_dcolor, a.dL_ddepth, a.dL_dalpha, grad_rec, blend_prefetch_lines())
     const bool depth = a.dL_ddepth != nullptr;
     if (a.geom_channels <= 0 || a.geom_channels >= C) {
         if (depth) OGS_BWD_LAUNCH(C, true); else OGS_BWD_LAUNCH(C, false);

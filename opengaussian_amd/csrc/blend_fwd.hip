@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ qcount, const float* __restrict__ stream,
     const uint32_t* __restrict__ quad_list, int W, int H, int gx, int tiles, const float* __restrict__ bg, float* __restrict__ out_color,
     float* __restrict__ out_depth, float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib,
-    float* __restrict__ final_T) {
+    float* __restrict__ final_T, int pf_lines) {
     constexpr int RS = stream_vec4(C) * 4;      // floats per stream record
     const int tile = blockIdx.x;                // virtual tile (grouped pass): image * tiles + tile in the image
     const int img = tile / tiles, timg = tile - img * tiles;
@@ -181,6 +181,8 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
     const uint32_t lim = n_tile > 0 ? (uint32_t)n_tile - 1u : 0u;
     // index -> record address; whatever the two-ahead prefetch reads past the end of the region is clamped
     auto rec_at = [&](uint32_t i) { return tb + (size_t)(min(i, lim) * (uint32_t)RS); };
+    RecordPrefetch pf;
+    pf.issue(tb, n_tile, RS, tid, pf_lines);
 
     // The loop is written to be SCALAR-ALU frugal (rocprof: the first version issued more SALU than VALU
     // instructions -- one scalar unit per CU -- because every nested divergent `if` costs exec-mask ops):
@@ -264,6 +266,7 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
         n_contrib[pix] = last;          // index into the QUADRANT stream (+1); see export_n_contrib_kernel
         final_T[pix] = T;               // the backward starts its T recursion from this, not from 1 - alpha
     }
+    pf.retire(n_contrib, W);
 }
 
 // test/diagnostic export: translate the per-quadrant stream index kept in n_contrib back to the reference's
@@ -434,7 +437,7 @@ int launch_c(const OgsRasterFwdArgs& a, const GeomState& gs, const ImageState& i
     OGS_LAUNCH_NAMED(chan_name<C>(kNames), blend_forward_kernel<C>, dim3(vtiles), dim3(kBlock), 0, s,
                      (const uint2*)is.ranges, (const uint32_t*)is.qcount, (const float*)stream_base<C>(a.sorted_rec),
                      (const uint32_t*)quad_base(a.quad_list), a.W, a.H, gx, tiles, a.bg, a.out_color, a.out_depth,
-                     a.out_alpha, is.n_contrib, is.final_T);
+                     a.out_alpha, is.n_contrib, is.final_T, blend_prefetch_lines());
     OGS_LAUNCH_CHECK(a.debug, s);
     return OGS_OK;
 }

@@ -61,6 +61,17 @@ static bool grad_accum_f64() {
     return v;
 }
 
+}  // namespace ogs (reopened below)
+int ogs::blend_prefetch_lines() {
+    static const int v = [] {
+        const char* e = getenv("OGS_BLEND_PREFETCH");
+        const int n = e ? atoi(e) : kPrefetchMax;
+        return n < 0 ? 0 : (n > kPrefetchMax ? kPrefetchMax : n);
+    }();
+    return v;
+}
+namespace ogs {
+
 static int bit_length(uint32_t v) {
     int n = 0;
     while (v) { ++n; v >>= 1; }

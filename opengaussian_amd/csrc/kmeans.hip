@@ -327,9 +327,11 @@ __global__ __launch_bounds__(kBlock) void kmeans_gather_kernel(const float* __re
     out[i] = centers[ids[row] * vec_dim + col];
 }
 
-// tuning knobs (A/B timing only): OGS_KM_PPL=1 -> one point per lane; OGS_KM_BLOCKS=n -> workgroups per pass
+// tuning knobs (A/B timing only): OGS_KM_PPL=2 -> two points per lane on packed fp32 ops (measured: no faster than
+// one -- 115-123 vs 112-118 us per accumulate pass at N = 2M, k = 64, d = 9: the pass is not VALU-issue bound, see
+// DESIGN.md section 4); OGS_KM_BLOCKS=n -> workgroups per pass
 inline int km_ppl() {
-    static const int v = [] { const char* e = getenv("OGS_KM_PPL"); return (e && atoi(e) == 1) ? 1 : 2; }();
+    static const int v = [] { const char* e = getenv("OGS_KM_PPL"); return (e && atoi(e) == 2) ? 2 : 1; }();
     return v;
 }
 inline int km_max_blocks() {

@@ -291,6 +291,34 @@ __device__ __forceinline__ float blend_power(float a2, float b2, float c2, float
     return fmaf(c2 * dy, dy, u * dx);              // (a2*dx + b2*dy)*dx + c2*dy^2
 }
 
+// ---- record prefetch of the blend kernels --------------------------------------------------------------------------
+// The blend loops read the tile's record stream through the SCALAR path (blend_fwd.hip), two batches in flight per
+// wave: with the stream coming from HBM (written by pack just before, far larger than L2) the loops are bound by
+// the latency of those scalar loads, not by VALU issue.  At kernel entry the four waves of a tile therefore touch
+// every 128-byte line of the tile's record range with plain vector loads -- all issued at once, never waited for
+// until the kernel's last instruction -- which pulls the range towards the XCD's L2 ahead of the scalar loads.
+// `lines` = 128-byte lines per thread (0: off; tuning knob OGS_BLEND_PREFETCH), `sink` is opaque to the compiler.
+constexpr int kPrefetchMax = 4;
+struct RecordPrefetch {
+    uint32_t v[kPrefetchMax];
+    __device__ __forceinline__ void issue(const float* __restrict__ tile_records, int n_tile, int rec_floats, int tid,
+                                          int lines) {
+        const uint32_t total = (uint32_t)n_tile * (uint32_t)rec_floats;          // floats in the tile's range
+#pragma unroll
+        for (int k = 0; k < kPrefetchMax; ++k) {
+            v[k] = 0u;
+            const uint32_t off = ((uint32_t)(k * kBlock + tid)) * 32u;            // one 128-byte line per thread and round
+            if (k < lines && off < total) v[k] = __float_as_uint(tile_records[off]);
+        }
+    }
+    // keeps the loads alive without ever waiting for them inside the loop: folded into a store that cannot happen
+    __device__ __forceinline__ void retire(uint32_t* __restrict__ sink, int never) const {
+        const uint32_t x = v[0] ^ v[1] ^ v[2] ^ v[3];
+        if (never < 0 && x == 0x7FC12345u) sink[0] = x;
+    }
+};
+int blend_prefetch_lines();     // capi.hip: OGS_BLEND_PREFETCH (default kPrefetchMax)
+
 // ---- tiny device helpers ------------------------------------------------------------------------
 // s_waitcnt lgkmcnt(0) (vmcnt / expcnt untouched), pinned in place: nothing is scheduled across it
 __device__ __forceinline__ void wait_scalar_loads() {
