@@ -465,11 +465,23 @@ def test_adversarial_scenes_forward_and_backward(gpu_device, kind, P, W, H):
                                   sh_degree=3)
     t = lambda a: torch.tensor(a, dtype=torch.float32, device=gpu_device)
     torch.autograd.backward([color, depth, alpha], [t(gC), t(gD), t(gA)])
+    problems = []
     for k in ("means3D", "scales", "rotations", "opacities", "shs", "means2D"):
         got = leaves[k].grad.cpu().double().numpy()
         want = gref[k].reshape(got.shape)
-        e = helpers.assert_grads_close_modulo_threshold_flips(got, want, GRAD_TOL, what=f"{kind} {k}")
-        print("adversarial", kind, k, f"{e:.1e} (rows that are not threshold flips)", f"{np.abs(got - want).max() / (np.abs(want).max() + 1e-12):.1e} (all)")
+        err = (np.abs(got - want) / (np.abs(want).max() + 1e-30)).reshape(P, -1).max(axis=1)
+        worst = np.argsort(-err)[:4]
+        print("adversarial", kind, k, "rows over tol:", int((err > GRAD_TOL).sum()), "worst rows", worst.tolist(),
+              [f"{err[r]:.1e}" for r in worst], "radii", ref["geom"].radii[worst].tolist(), "depth", ref["geom"].depth[worst].tolist(),
+              "opacity", [f"{float(sc.opacities[r]):.3f}" for r in worst])
+        try:
+            helpers.assert_grads_close_modulo_threshold_flips(got, want, GRAD_TOL, flip_tol=5e-2, what=f"{kind} {k}")
+        except AssertionError as e:
+            problems.append(str(e))
+    # pixels where the device and the fp32 oracle disagree on the last contributor: the threshold flips
+    flips = np.argwhere(ncontrib != ref["n_contrib"].astype(np.uint32))
+    print("adversarial", kind, "n_contrib flips at pixels", flips[:8].tolist())
+    assert not problems, problems
 
 
 @pytest.mark.parametrize("use_sh,G", [(False, 5), (True, 3), (False, 37)])
