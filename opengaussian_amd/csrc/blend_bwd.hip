@@ -40,18 +40,18 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 //   A operand of MFMA j, lane l: W[entry l % 16][pixel 4 j + l / 16]   (read back transposed from LDS)
 //   B operand of MFMA j, lane l: G[pixel 4 j + l / 16][channel l % 16] (loop invariant: 16 registers per lane)
 //   D, lane l, register r:       entry 4 (l / 16) + r, channel l % 16
-// LDS: 16 x 66 floats per wave (row stride 66 words: the transposed read is bank-conflict free) + 16 Gaussian ids.
+// LDS: 16 x 66 floats per wave (row stride 66 words: the transposed read is bank-conflict free).  The sixteen
+// Gaussian ids of a batch live in ONE VGPR (entry e in lane e: a select per entry, no exec-mask region) and are fetched for the atomics with ds_bpermute.
 constexpr int kFoldRows = 16;
 constexpr int kFoldStride = 66;
 struct WaveFoldLds {
     float w[kFoldRows * kFoldStride];
-    uint32_t gid[kFoldRows];
 };
 
 template <int NCH, int SLOT0, int GS, typename ACC>
 struct RankOneFold {
     float* w;
-    uint32_t* gid;
+    uint32_t gidv;  // lane e: Gaussian id of staged entry e
     float B[16];
     int cnt;        // wave-uniform: entries staged
 
@@ -59,7 +59,7 @@ struct RankOneFold {
     template <typename F>
     __device__ __forceinline__ void init(WaveFoldLds* lds, int lane, int tx, int ty, int wave, int W, int H, F gmap) {
         w = lds->w;
-        gid = lds->gid;
+        gidv = 0u;
         cnt = 0;
         const int n = lane & 15, kq = lane >> 4;
 #pragma unroll
@@ -82,14 +82,15 @@ struct RankOneFold {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int e = 4 * kq + r;
-            if (e < cnt && m < NCH) atomicAdd(grad_rec + (size_t)gid[e] * GS + SLOT0 + m, (ACC)d[r]);
+            const uint32_t g = (uint32_t)__builtin_amdgcn_ds_bpermute(e * 4, (int)gidv);
+            if (e < cnt && m < NCH) atomicAdd(grad_rec + (size_t)g * GS + SLOT0 + m, (ACC)d[r]);
         }
         cnt = 0;
     }
     // one accepted entry: this lane's weight, the entry's Gaussian (wave-uniform)
     __device__ __forceinline__ void push(float wl, uint32_t g, ACC* __restrict__ grad_rec, int lane) {
         w[cnt * kFoldStride + lane] = wl;
-        if (lane == 0) gid[cnt] = g;
+        gidv = lane == cnt ? g : gidv;                 // a select, not a branch
         ++cnt;
         if (cnt == kFoldRows) flush(grad_rec, lane);
     }

@@ -472,15 +472,19 @@ def render_forward(means3D, opacities, viewmatrix, projmatrix, campos, W, H, tan
 
 
 def render_backward_f64(inputs: dict, binning: Binning, W, H, tanfovx, tanfovy, bg,
-                        dL_dcolor, dL_ddepth, dL_dalpha, scale_modifier=1.0, sh_degree=0, tiles=None):
+                        dL_dcolor, dL_ddepth, dL_dalpha, scale_modifier=1.0, sh_degree=0, tiles=None,
+                        dtype=torch.float64):
     """float64 autograd through preprocess_t + blend with the float32 binning held fixed.
     ``inputs``: dict of numpy arrays with keys means3D, opacities, viewmatrix, projmatrix, campos and
     scales+rotations | cov3D_precomp, shs | colors_precomp.  Returns dict of gradients (numpy f64),
     including 'means2D' ([P,3], z = 0).
     ``tiles``: optional list of tile ids -- only those tiles are blended (a bounded sample of a full-size
     scene: the caller passes upstream gradients that are zero outside them, so the result is the exact gradient
-    of that loss)."""
-    t64 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+    of that loss).
+    ``dtype``: torch.float64 is the gradient oracle.  torch.float32 evaluates the SAME graph in fp32 -- what any fp32
+    implementation of the algorithm computes, skip decisions (alpha >= 1/255, T < 1e-4) included: the tests use it to
+    attribute the rare Gaussian whose gradient differs from the float64 one because a decision flips in fp32."""
+    t64 = lambda a: torch.tensor(np.asarray(a), dtype=dtype)
     # Only Gaussians that appear in a tile list receive gradient; restrict the graph to them so
     # culled rows (pvz<=0.2, det==0) cannot inject 0*inf NaNs, then scatter back.
     P_all = np.asarray(inputs["means3D"]).shape[0]
@@ -499,7 +503,7 @@ def render_backward_f64(inputs: dict, binning: Binning, W, H, tanfovx, tanfovy, 
         if inputs.get(k) is not None:
             leaves[k] = t64(np.asarray(inputs[k])[used]).requires_grad_(True)
     P = leaves["means3D"].shape[0]
-    leaves["means2D"] = torch.zeros(P, 3, dtype=torch.float64, requires_grad=True)
+    leaves["means2D"] = torch.zeros(P, 3, dtype=dtype, requires_grad=True)
     xy, conic, op, rgb, depth = preprocess_t(
         leaves["means3D"], leaves["means2D"], leaves["opacities"], t64(inputs["viewmatrix"]),
         t64(inputs["projmatrix"]), t64(inputs["campos"]).reshape(3), W, H, float(tanfovx), float(tanfovy),
@@ -516,6 +520,6 @@ def render_backward_f64(inputs: dict, binning: Binning, W, H, tanfovx, tanfovy, 
             out[n] = None
             continue
         full = np.zeros((P_all,) + tuple(g.shape[1:]), dtype=np.float64)
-        full[used] = g.numpy()
+        full[used] = g.double().numpy()
         out[n] = full
     return out

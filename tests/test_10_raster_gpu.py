@@ -172,13 +172,15 @@ def _grad_check(inp, cam, W, H, f, device, sh_degree=3, bg=(0.1, 0.2, 0.3), seed
     t = lambda a: torch.tensor(a, dtype=torch.float32, device=device)
     loss = (color * t(gC)).sum() + (depth * t(gD)).sum() + (alpha * t(gA)).sum()
     loss.backward()
+    g32 = helpers.lazy(lambda: ro.render_backward_f64(inp, ref["binning"], W, H, W / (2 * f), H / (2 * f), np.array(bg, np.float64),
+                                                      gC, gD, gA, sh_degree=sh_degree, dtype=torch.float32))
     out = {}
     for k, v in leaves.items():
         if v is None or gref.get(k) is None:
             continue
         got = v.grad.detach().cpu().double().numpy()
         want = gref[k].reshape(got.shape)
-        out[k] = helpers.assert_grads_close_modulo_threshold_flips(got, want, GRAD_TOL, what=k)
+        out[k] = helpers.assert_grads_close_modulo_threshold_flips(got, want, GRAD_TOL, want_fp32=lambda k=k: g32()[k], what=k)
     return out
 
 
@@ -465,23 +467,15 @@ def test_adversarial_scenes_forward_and_backward(gpu_device, kind, P, W, H):
                                   sh_degree=3)
     t = lambda a: torch.tensor(a, dtype=torch.float32, device=gpu_device)
     torch.autograd.backward([color, depth, alpha], [t(gC), t(gD), t(gA)])
-    problems = []
+    g32 = helpers.lazy(lambda: ro.render_backward_f64(inp, ref["binning"], W, H, W / (2 * f), H / (2 * f), np.array(bg, np.float64),
+                                                      gC, gD, gA, sh_degree=3, dtype=torch.float32))
     for k in ("means3D", "scales", "rotations", "opacities", "shs", "means2D"):
         got = leaves[k].grad.cpu().double().numpy()
         want = gref[k].reshape(got.shape)
-        err = (np.abs(got - want) / (np.abs(want).max() + 1e-30)).reshape(P, -1).max(axis=1)
-        worst = np.argsort(-err)[:4]
-        print("adversarial", kind, k, "rows over tol:", int((err > GRAD_TOL).sum()), "worst rows", worst.tolist(),
-              [f"{err[r]:.1e}" for r in worst], "radii", ref["geom"].radii[worst].tolist(), "depth", ref["geom"].depth[worst].tolist(),
-              "opacity", [f"{float(sc.opacities[r]):.3f}" for r in worst])
-        try:
-            helpers.assert_grads_close_modulo_threshold_flips(got, want, GRAD_TOL, flip_tol=5e-2, what=f"{kind} {k}")
-        except AssertionError as e:
-            problems.append(str(e))
-    # pixels where the device and the fp32 oracle disagree on the last contributor: the threshold flips
-    flips = np.argwhere(ncontrib != ref["n_contrib"].astype(np.uint32))
-    print("adversarial", kind, "n_contrib flips at pixels", flips[:8].tolist())
-    assert not problems, problems
+        e = helpers.assert_grads_close_modulo_threshold_flips(got, want, GRAD_TOL, want_fp32=lambda k=k: g32()[k],
+                                                              what=f"{kind} {k}")
+        print("adversarial", kind, k, f"{e:.1e} (rows held to the float64 oracle)",
+              f"{np.abs(got - want).max() / (np.abs(want).max() + 1e-12):.1e} (all rows)")
 
 
 @pytest.mark.parametrize("use_sh,G", [(False, 5), (True, 3), (False, 37)])
@@ -586,7 +580,10 @@ def test_sh_degrees_coefficient_counts_and_scale_modifier(gpu_device, sh_degree,
             continue
         got = leaves[k].grad.cpu().double().numpy()
         want = gref[k].reshape(got.shape)
-        helpers.assert_grads_close_modulo_threshold_flips(got, want, GRAD_TOL, what=k)
+        helpers.assert_grads_close_modulo_threshold_flips(
+            got, want, GRAD_TOL, what=k, want_fp32=lambda k=k: ro.render_backward_f64(
+                inp, ref["binning"], W, H, W / (2 * f), H / (2 * f), np.array(bg, np.float64), gC, gD, gA, sh_degree=sh_degree,
+                scale_modifier=scale_modifier, dtype=torch.float32)[k])
     if sh_coeffs > (sh_degree + 1) ** 2:                  # coefficients above the active degree get exact zeros
         assert float(leaves["shs"].grad[:, (sh_degree + 1) ** 2:].abs().max()) == 0.0
 

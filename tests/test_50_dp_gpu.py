@@ -188,9 +188,12 @@ def _sharded_adam_rank(rank, world, port, q):
             gr = torch.Generator().manual_seed(100 * it + r)
             for n, s in shapes:
                 v = torch.randn(*s, generator=gr).to(dev)
-                total[n] = v if n not in total else total[n] + v
+                # it == 3: rank 1's view saw nothing of `opacity` -> its .grad is None (contributes zeros), the step happens
+                absent = it == 3 and r == 1 and n == "opacity"
+                if not absent:
+                    total[n] = v if n not in total else total[n] + v
                 if r == rank:
-                    opt.params[n].grad = v
+                    opt.params[n].grad = None if absent else v
         # torch.optim.Adam semantics per parameter: no gradient on ANY rank -> the parameter is skipped
         # (value, moments and its own step counter untouched); ins_feat starts late, rotation pauses at step 2
         skipped = set()
@@ -200,15 +203,6 @@ def _sharded_adam_rank(rank, world, port, q):
             skipped.add("rotation")
         for n in skipped:
             opt.params[n].grad = None
-        if it == 3 and rank == 1:
-            # None on ONE rank only (its view saw nothing of that tensor): it contributes zeros, the step happens
-            opt.params["opacity"].grad = None
-        if it == 3:
-            gr1 = torch.Generator().manual_seed(100 * it + 1)
-            for n, s in shapes:
-                v = torch.randn(*s, generator=gr1).to(dev)
-                if n == "opacity":
-                    total[n] = total[n] - v
         opt.step()
         for n, _ in shapes:
             ref_params[n].grad = None if n in skipped else total[n].clone()
