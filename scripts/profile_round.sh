@@ -16,21 +16,5 @@ echo "[profile] FETCH_SIZE";   rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o f -- 
 echo "[profile] WRITE_SIZE";   rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o w -- $BENCH > $OUT/write.log 2>&1
 echo "[profile] SQ insts";     rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES -d $OUT/sq1 -o s -- $BENCH > $OUT/sq1.log 2>&1
 echo "[profile] SQ cycles";    rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM -d $OUT/sq2 -o s -- $BENCH > $OUT/sq2.log 2>&1 || true
-STATS=$(find $OUT/trace -name '*kernel_stats.csv' | head -1)
-cp "$STATS" profiles/${TAG}_kernel_stats.csv
-python3 scripts/collect_pmc.py $OUT/fetch $OUT/write profiles/${TAG}_pmc_fetch_write_per_launch.json profiles/pmc_traffic.json
-python3 scripts/collect_sq.py profiles/${TAG}_sq_counters_per_launch.json $OUT/sq1 $OUT/sq2
-python3 - <<PY
-import json, subprocess
-from opengaussian_amd import _lib
-ver = int(_lib.lib().ogs_version())
-src = "scripts/profile_round.sh $TAG: rocprofv3 --pmc passes of '$BENCH' (S1M-1080p fused pass, 8 views cycled)"
-t = json.load(open("profiles/pmc_traffic.json")); t["_ogs_version"] = ver; t["_source"] = src + "; bytes = 2*FETCH_SIZE + WRITE_SIZE (KiB -> B), per launch"
-json.dump(t, open("profiles/pmc_traffic.json", "w"), indent=1)
-sq = json.load(open("profiles/${TAG}_sq_counters_per_launch.json"))
-out = {k: {"SQ_INSTS_VALU": v.get("SQ_INSTS_VALU"), "SQ_INSTS_SALU": v.get("SQ_INSTS_SALU"), "SQ_INSTS_SMEM": v.get("SQ_INSTS_SMEM"), "SQ_WAVES": v.get("SQ_WAVES")} for k, v in sq.items() if "SQ_INSTS_VALU" in v}
-out["_ogs_version"] = ver; out["_source"] = src + "; per-launch averages"
-json.dump(out, open("profiles/sq_valu.json", "w"), indent=1)
-print("profiles written for ogs_version", ver)
-PY
-head -25 profiles/${TAG}_kernel_stats.csv
+VER=$(python3 -c "from opengaussian_amd import _lib; print(int(_lib.lib().ogs_version()))")
+python3 scripts/collect_rocpd.py $OUT $TAG $VER "$BENCH"
