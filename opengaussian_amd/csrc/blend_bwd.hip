@@ -110,7 +110,7 @@ template <int C, int GC, bool DEPTH, typename ACC>
 __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     const uint2* __restrict__ ranges, const float* __restrict__ stream, const uint32_t* __restrict__ quad_list, int W,
     int H, int gx, int tiles, const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-    const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha_map,
+    const uint32_t* __restrict__ qcount, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha_map,
     ACC* __restrict__ grad_rec, int pf_lines) {
     constexpr int RS = stream_vec4(C) * 4;
     constexpr int GS = grad_stride(C);
@@ -139,11 +139,12 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     // this wave's quadrant stream (blend_fwd.hip::pack_sorted_kernel); n_contrib indexes into it
     const int n_tile = (int)(range.y - range.x);
     const float* __restrict__ tb = stream + (size_t)range.x * RS;                                    // tile's records
-    const uint32_t* __restrict__ qi = quad_list + ((size_t)range.x * 4 + (size_t)wave * n_tile);     // quadrant's indices
-    const uint32_t lim = n_tile > 0 ? (uint32_t)n_tile - 1u : 0u;
+    const uint32_t* __restrict__ qi = quad_list + ((size_t)range.x * 5 + (size_t)wave * n_tile);     // quadrant's indices
+    const int n_kept = (int)qcount[tile * 5 + 4];                                                     // compacted records of the tile
+    const uint32_t lim = n_kept > 0 ? (uint32_t)n_kept - 1u : 0u;
     auto rec_at = [&](uint32_t i) { return tb + (size_t)(min(i, lim) * (uint32_t)RS); };
     RecordPrefetch pf;
-    pf.issue(tb, n_tile, RS, tid, pf_lines);
+    pf.issue(tb, n_kept, RS, tid, pf_lines);
 
     const float T_final = inside ? final_T[pix] : 0.f;      // the forward's own value (ImageState::final_T)
     float T = T_final;
@@ -271,8 +272,8 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
 template <int C, int F0, typename ACC>
 __global__ __launch_bounds__(kBlock) void blend_backward_feat_kernel(
     const uint2* __restrict__ ranges, const float* __restrict__ stream, const uint32_t* __restrict__ quad_list, int W,
-    int H, int gx, int tiles, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dcolor,
-    ACC* __restrict__ grad_rec, int pf_lines) {
+    int H, int gx, int tiles, const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ qcount,
+    const float* __restrict__ dL_dcolor, ACC* __restrict__ grad_rec, int pf_lines) {
     constexpr int RS = stream_vec4(C) * 4;
     constexpr int GS = grad_stride(C);
     constexpr int NS = C - F0;
@@ -297,11 +298,12 @@ __global__ __launch_bounds__(kBlock) void blend_backward_feat_kernel(
     if (hi == 0) return;
     const int n_tile = (int)(range.y - range.x);
     const float* __restrict__ tb = stream + (size_t)range.x * RS;
-    const uint32_t* __restrict__ qi = quad_list + ((size_t)range.x * 4 + (size_t)wave * n_tile);
-    const uint32_t lim = n_tile > 0 ? (uint32_t)n_tile - 1u : 0u;
+    const uint32_t* __restrict__ qi = quad_list + ((size_t)range.x * 5 + (size_t)wave * n_tile);
+    const int n_kept = (int)qcount[tile * 5 + 4];
+    const uint32_t lim = n_kept > 0 ? (uint32_t)n_kept - 1u : 0u;
     auto rec_at = [&](uint32_t i) { return tb + (size_t)(min(i, lim) * (uint32_t)RS); };
     RecordPrefetch pf;
-    pf.issue(tb, n_tile, RS, tid, pf_lines);
+    pf.issue(tb, n_kept, RS, tid, pf_lines);
 
     // the whole reduction is rank one: every slot goes through the matrix cores (RankOneFold above)
     RankOneFold<NS, F0, GS, ACC> fold;
@@ -377,7 +379,7 @@ int launch_c(const OgsRasterBwdArgs& a, const ImageState& is, void* grad_rec_, h
 #define OGS_BWD_FEAT(F0V)                                                                                             \
     OGS_LAUNCH_NAMED(chan_name<C>(kFeatNames), (blend_backward_feat_kernel<C, F0V, ACC>), dim3(vtiles), dim3(kBlock), 0, \
                      s, (const uint2*)is.ranges, stream, quads, a.W, a.H, gx, gx * gy, (const uint32_t*)is.n_contrib,    \
-                     a.dL_dcolor, grad_rec, blend_prefetch_lines())
+                     (const uint32_t*)is.qcount, a.dL_dcolor, grad_rec, blend_prefetch_lines())
         if constexpr (C > 3) {
             if (a.shs != nullptr) OGS_BWD_FEAT(3); else OGS_BWD_FEAT(0);
         } else {
@@ -390,7 +392,8 @@ int launch_c(const OgsRasterBwdArgs& a, const ImageState& is, void* grad_rec_, h
 #define OGS_BWD_LAUNCH(GCV, DEPTHV)                                                                                  \
     OGS_LAUNCH_NAMED(chan_name<C>(kNames), (blend_backward_kernel<C, GCV, DEPTHV, ACC>), dim3(vtiles), dim3(kBlock), 0, s, \
                      (const uint2*)is.ranges, stream, quads, a.W, a.H, gx, gx * gy, a.bg, (const float*)is.final_T,                  \
-                     (const uint32_t*)is.n_contrib, a.dL_dcolor, a.dL_ddepth, a.dL_dalpha, grad_rec, blend_prefetch_lines())
+                     (const uint32_t*)is.n_contrib, (const uint32_t*)is.qcount, a.dL_dcolor, a.dL_ddepth, a.dL_dalpha, grad_rec,  \
+                     blend_prefetch_lines())
     const bool depth = a.dL_ddepth != nullptr;
     if (a.geom_channels <= 0 || a.geom_channels >= C) {
         if (depth) OGS_BWD_LAUNCH(C, true); else OGS_BWD_LAUNCH(C, false);

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(kBlock) void pack_sorted_kernel(const uint2* __rest
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
     const float X0 = (float)((timg % gx) * kTile), Y0 = (float)((timg / gx) * kTile);
-    uint32_t running[4] = {0u, 0u, 0u, 0u};                // kept entries per quadrant so far (block-uniform)
+    uint32_t running[5] = {0u, 0u, 0u, 0u, 0u};            // kept entries so far: per quadrant, and by the tile (block-uniform)
 
     for (int base = 0; base < n; base += kBlock) {
         const int i = base + tid;
@@ -99,9 +99,10 @@ __global__ __launch_bounds__(kBlock) void pack_sorted_kernel(const uint2* __rest
                 if (m >= thr) mask |= 1u << q;
             }
         }
-        // block-wide exclusive prefix of the four per-quadrant keep flags (16-bit lanes of one u64)
-        const uint64_t mine = (uint64_t)(mask & 1u) | ((uint64_t)((mask >> 1) & 1u) << 16) |
-                              ((uint64_t)((mask >> 2) & 1u) << 32) | ((uint64_t)((mask >> 3) & 1u) << 48);
+        // block-wide exclusive prefix of the four per-quadrant keep flags and of "kept at all" (12-bit fields of one u64)
+        const uint64_t mine = (uint64_t)(mask & 1u) | ((uint64_t)((mask >> 1) & 1u) << 12) |
+                              ((uint64_t)((mask >> 2) & 1u) << 24) | ((uint64_t)((mask >> 3) & 1u) << 36) |
+                              ((uint64_t)(mask != 0u ? 1u : 0u) << 48);
         uint64_t inc = mine;
 #pragma unroll
         for (int d = 1; d < kWave; d <<= 1) {
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(kBlock) void pack_sorted_kernel(const uint2* __rest
         }
         if (lane == kWave - 1) wave_tot[wave] = inc;
         __syncthreads();
-        uint64_t before = 0, total = 0;                    // chunk-local: every 16-bit field <= 256
+        uint64_t before = 0, total = 0;                    // chunk-local: every 12-bit field <= 256
 #pragma unroll
         for (int w = 0; w < kBlock / kWave; ++w) {
             const uint64_t t = wave_tot[w];
@@ -119,9 +120,10 @@ __global__ __launch_bounds__(kBlock) void pack_sorted_kernel(const uint2* __rest
         }
         const uint64_t pos = before + inc - mine;          // exclusive position inside this chunk, per quadrant
         if (mask) {
-            // ONE copy of the record, at the entry's own position in the tile list (consecutive threads ->
-            // consecutive 16*SV-byte records) ...
-            float4* dst = stream + ((size_t)range.x + (size_t)i) * SV;
+            // ONE copy of the record, COMPACTED: kept entry number c of the tile goes to record range.x + c (depth
+            // order preserved; consecutive kept threads -> consecutive 16*SV-byte records) ...
+            const uint32_t c_idx = running[4] + ((uint32_t)(pos >> 48) & 0xFFFu);
+            float4* dst = stream + ((size_t)range.x + (size_t)c_idx) * SV;
             dst[0] = make_float4(a.x, a.y, -0.5f * b.x, -b.y);
             dst[1] = make_float4(-0.5f * b.z, h, b.w, __uint_as_float(gid_of_thread));
             // features (gathered only now: 52 % of the bench scene's entries reach no quadrant), then the view
@@ -138,22 +140,24 @@ __global__ __launch_bounds__(kBlock) void pack_sorted_kernel(const uint2* __rest
             f[C] = a.z;
 #pragma unroll
             for (int v = 0; v < SV - 2; ++v) dst[2 + v] = make_float4(f[4 * v], f[4 * v + 1], f[4 * v + 2], f[4 * v + 3]);
-            // ... and its tile-local index appended to the index stream of every quadrant it can reach
+            // ... its compact index appended to the index stream of every quadrant it can reach, and its position in
+            // the tile's full list kept for the n_contrib export
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (mask & (1u << q)) {
-                    const uint32_t p = running[q] + ((uint32_t)(pos >> (16 * q)) & 0xFFFFu);
-                    quad_list[(size_t)range.x * 4 + (size_t)q * n + p] = (uint32_t)i;
+                    const uint32_t p = running[q] + ((uint32_t)(pos >> (12 * q)) & 0xFFFu);
+                    quad_list[(size_t)range.x * 5 + (size_t)q * n + p] = c_idx;
                 }
             }
+            quad_list[(size_t)range.x * 5 + (size_t)4 * n + c_idx] = (uint32_t)i;
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) running[q] += (uint32_t)(total >> (16 * q)) & 0xFFFFu;
+        for (int q = 0; q < 5; ++q) running[q] += (uint32_t)(total >> (12 * q)) & 0xFFFu;
         __syncthreads();
     }
     if (tid == 0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) qcount[tile * 4 + q] = running[q];
+        for (int q = 0; q < 5; ++q) qcount[tile * 5 + q] = running[q];
     }
 }
 
@@ -175,10 +179,11 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
 
     const uint2 range = ranges[tile];
     const int n_tile = (int)(range.y - range.x);
-    const int n = (int)qcount[tile * 4 + wave];                        // this quadrant's kept entries
+    const int n = (int)qcount[tile * 5 + wave];                        // this quadrant's kept entries
+    const int n_kept = (int)qcount[tile * 5 + 4];                      // records the tile keeps (compacted)
     const float* __restrict__ tb = stream + (size_t)range.x * RS;                                    // tile's records
-    const uint32_t* __restrict__ qi = quad_list + ((size_t)range.x * 4 + (size_t)wave * n_tile);     // quadrant's indices
-    const uint32_t lim = n_tile > 0 ? (uint32_t)n_tile - 1u : 0u;
+    const uint32_t* __restrict__ qi = quad_list + ((size_t)range.x * 5 + (size_t)wave * n_tile);     // quadrant's indices
+    const uint32_t lim = n_kept > 0 ? (uint32_t)n_kept - 1u : 0u;
     // index -> record address; whatever the two-ahead prefetch reads past the end of the region is clamped
     auto rec_at = [&](uint32_t i) { return tb + (size_t)(min(i, lim) * (uint32_t)RS); };
     RecordPrefetch pf;
@@ -291,7 +296,10 @@ __global__ __launch_bounds__(kBlock) void export_n_contrib_kernel(const uint2* _
     const uint32_t last = n_contrib[(size_t)py * W + px];
     // n_contrib counts inside the quadrant's index stream; the stream entry IS the position in the tile list
     uint32_t res = 0;
-    if (last > 0) res = quad_list[(size_t)range.x * 4 + (size_t)wave * n_tile + (last - 1)] + 1u;
+    if (last > 0) {
+        const uint32_t c_idx = quad_list[(size_t)range.x * 5 + (size_t)wave * n_tile + (last - 1)];
+        res = quad_list[(size_t)range.x * 5 + (size_t)4 * n_tile + c_idx] + 1u;       // compact index -> full-list position
+    }
     out[(size_t)py * W + px] = res;
 }
 
@@ -430,7 +438,7 @@ int launch_c(const OgsRasterFwdArgs& a, const GeomState& gs, const ImageState& i
                          stream_base<C>(a.sorted_rec), quad_base(a.quad_list), is.qcount);
         OGS_LAUNCH_CHECK(a.debug, s);
     } else {
-        OGS_HIP_CHECK(hipMemsetAsync(is.qcount, 0, (size_t)vtiles * 4 * sizeof(uint32_t), s));
+        OGS_HIP_CHECK(hipMemsetAsync(is.qcount, 0, (size_t)vtiles * 5 * sizeof(uint32_t), s));
     }
     static constexpr const char* const kNames[4] = {"blend_forward_kernel<3>", "blend_forward_kernel<6>",
                                                     "blend_forward_kernel<9>", "blend_forward_kernel<12>"};

@@ -168,9 +168,9 @@ size_t ogs_raster_sorted_bytes(int64_t D, int32_t C) {
     return align_up((size_t)(D > 0 ? D : 1) * stream_vec4(C) * sizeof(float4));
 }
 size_t ogs_raster_quad_list_bytes(int64_t D) {
-    // four quadrant regions of capacity n_tile per tile (only the kept ~1.1 x D indices are written) + slack for the
-    // blend loops' two-ahead index prefetch on either side
-    return align_up((size_t)(4 * (D > 0 ? D : 1) + 2 * kQuadPad) * sizeof(uint32_t));
+    // per tile four quadrant regions + the full-list positions, each of capacity n_tile (only the kept ~1.1 x D
+    // indices and ~0.5 x D positions are written) + slack for the blend loops' two-ahead index prefetch on either side
+    return align_up((size_t)(5 * (D > 0 ? D : 1) + 2 * kQuadPad) * sizeof(uint32_t));
 }
 size_t ogs_raster_backward_tmp_bytes(int32_t P) { return align_up((size_t)(P > 0 ? P : 1) * 16 * sizeof(double)); }
 

@@ -90,11 +90,13 @@ __host__ __device__ constexpr int rec_vec4(int C) { return 2 + (C + 3) / 4; }   
 __host__ __device__ constexpr int stream_vec4(int C) { return (8 + C + 1 + 3) / 4; }
 
 // Blend-side layout (blend_fwd.hip): `sorted_rec` holds ONE packed record per entry of the sorted (Gaussian, tile)
-// list, at the entry's position (written only when some quadrant of the tile can be reached); `quad_list` holds,
-// per (tile, 8x8 quadrant), the tile-local indices of the entries that quadrant keeps, depth order preserved:
-// region of quadrant q of a tile with list [start, start + n) = quad_list[4*start + q*n ... + n).  The blend
-// loops prefetch two indices past either end of a region (kQuadPad u32 of slack in front and behind) and clamp
-// whatever they read to [0, n-1] before touching a record.
+// list that some quadrant of the tile can reach, COMPACTED: the k kept entries of a tile with list
+// [start, start + n) sit at records start .. start + k - 1, depth order preserved (the other n - k slots of the
+// tile's range stay unused).  `quad_list` holds, per tile, five regions of n u32 at 5*start: for each 8x8
+// quadrant q the compact indices (0 .. k-1) of the entries that quadrant keeps, depth order preserved
+// (5*start + q*n ...), and the position of every kept entry in the tile's FULL list (5*start + 4*n + compact index;
+// read only by the n_contrib export).  The blend loops prefetch two indices past either end of a region
+// (kQuadPad u32 of slack in front and behind) and clamp whatever they read to [0, k-1] before touching a record.
 constexpr int kQuadPad = 16;
 template <int C>
 inline float4* stream_base(void* buf) { return static_cast<float4*>(buf); }
@@ -150,7 +152,7 @@ struct GeomState {      // kept until backward
 struct ImageState {     // kept until backward
     uint2* ranges;          // [tiles] range of the tile in the sorted list (reference-exact)
     uint32_t* n_contrib;    // [W*H] last contributor, as 1-based index into the pixel's QUADRANT stream
-    uint32_t* qcount;       // [tiles*4] entries kept in each 8x8 quadrant stream
+    uint32_t* qcount;       // [tiles*5] entries kept in each 8x8 quadrant stream (4) + records kept by the tile (1)
     float* final_T;         // [W*H] transmittance left after the last contributor, exactly as the forward loop held it.
                             // The upstream backward re-derives it as 1 - out_alpha (Appendix A.4), which in fp32 loses
                             // up to eps / T_final = 6e-4 relative on saturated pixels (T_final -> 1e-4) and scales every
@@ -162,7 +164,7 @@ struct ImageState {     // kept until backward
         const size_t tiles = (size_t)G * ((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile);
         s.ranges = c.take<uint2>(tiles);
         s.n_contrib = c.take<uint32_t>((size_t)G * W * H);
-        s.qcount = c.take<uint32_t>(tiles * 4);
+        s.qcount = c.take<uint32_t>(tiles * 5);
         s.final_T = c.take<float>((size_t)G * W * H);
         return s;
     }
@@ -171,7 +173,7 @@ struct ImageState {     // kept until backward
         const size_t tiles = (size_t)G * ((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile);
         c.take<uint2>(tiles);
         c.take<uint32_t>((size_t)G * W * H);
-        c.take<uint32_t>(tiles * 4);
+        c.take<uint32_t>(tiles * 5);
         c.take<float>((size_t)G * W * H);
         return c.off;
     }
