@@ -48,6 +48,16 @@ struct WaveFoldLds {
     float w[kFoldRows * kFoldStride];
 };
 
+// no-return atomic add at (wave-uniform 64-bit base in SGPRs) + (32-bit per-lane byte offset): the SGPR-base addressing
+// form of global_atomic_add, which hipcc does not select by itself for atomics (it materialises a 64-bit VGPR address
+// per lane: two moves and a v_lshl_add_u64 per entry in the hot loop)
+__device__ __forceinline__ void atomic_add_sbase(double* base_uniform, uint32_t byte_off, double v) {
+    asm volatile("global_atomic_add_f64 %0, %1, %2" : : "v"(byte_off), "v"(v), "s"(base_uniform) : "memory");
+}
+__device__ __forceinline__ void atomic_add_sbase(float* base_uniform, uint32_t byte_off, float v) {
+    asm volatile("global_atomic_add_f32 %0, %1, %2" : : "v"(byte_off), "v"(v), "s"(base_uniform) : "memory");
+}
+
 template <int NCH, int SLOT0, int GS, typename ACC>
 struct RankOneFold {
     float* w;
@@ -83,7 +93,9 @@ struct RankOneFold {
         for (int r = 0; r < 4; ++r) {
             const int e = 4 * kq + r;
             const uint32_t g = (uint32_t)__builtin_amdgcn_ds_bpermute(e * 4, (int)gidv);
-            if (e < cnt && m < NCH) atomicAdd(grad_rec + (size_t)g * GS + SLOT0 + m, (ACC)d[r]);
+            // 32-bit element offset from the (uniform) record array: SGPR-base addressing
+            const uint32_t off = g * (uint32_t)GS + (uint32_t)(SLOT0 + m);
+            if (e < cnt && m < NCH) atomicAdd(grad_rec + off, (ACC)d[r]);
         }
         cnt = 0;
     }
@@ -236,10 +248,12 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
             v[5] = sG;
             v[6] = 0.f; v[7] = 0.f;
             const float y = wave_fold8(v);
-            const int slot = lane >> 3;
-            if ((lane & 7) == 0 && slot < 6) {
-                const uint32_t gid = __float_as_uint(cur[7]);
-                atomicAdd(grad_rec + (size_t)gid * GS + (C + 1) + slot, (ACC)y);
+            const uint32_t slot = (uint32_t)lane >> 3;
+            if ((lane & 7) == 0 && slot < 6u) {
+                // wave-uniform record base (scalar registers) + a 32-bit lane offset: the atomic takes the
+                // SGPR-base addressing form, no 64-bit VALU address arithmetic per entry
+                const uint32_t gid = __builtin_amdgcn_readfirstlane(__float_as_uint(cur[7]));
+                atomic_add_sbase(grad_rec + ((size_t)gid * GS + (C + 1)), slot * (uint32_t)sizeof(ACC), (ACC)y);
             }
         }
     };
