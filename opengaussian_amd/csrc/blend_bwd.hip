@@ -58,7 +58,9 @@ __device__ __forceinline__ void atomic_add_sbase(float* base_uniform, uint32_t b
     asm volatile("global_atomic_add_f32 %0, %1, %2" : : "v"(byte_off), "v"(v), "s"(base_uniform) : "memory");
 }
 
-template <int NCH, int SLOT0, int GS, typename ACC>
+// WIDE: all sixteen LDS reads in flight and four independent MFMA chains (the features-only kernel has the
+// registers for it and, with little VALU work per entry, feels the latency of a serial flush the most)
+template <int NCH, int SLOT0, int GS, typename ACC, bool WIDE = false>
 struct RankOneFold {
     float* w;
     uint32_t gidv;  // lane e: Gaussian id of staged entry e
@@ -84,10 +86,25 @@ struct RankOneFold {
     __device__ __forceinline__ void flush(ACC* __restrict__ grad_rec, int lane) {
         const int m = lane & 15, kq = lane >> 4;
         floatx4 d = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (WIDE) {
+            float a[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const float a = m < cnt ? w[m * kFoldStride + 4 * j + kq] : 0.f;
-            d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, B[j], d, 0, 0, 0);
+            for (int j = 0; j < 16; ++j) a[j] = m < cnt ? w[m * kFoldStride + 4 * j + kq] : 0.f;
+            floatx4 d1 = d, d2 = d, d3 = d;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * j], B[4 * j], d, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * j + 1], B[4 * j + 1], d1, 0, 0, 0);
+                d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * j + 2], B[4 * j + 2], d2, 0, 0, 0);
+                d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * j + 3], B[4 * j + 3], d3, 0, 0, 0);
+            }
+            d = (d + d1) + (d2 + d3);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float a = m < cnt ? w[m * kFoldStride + 4 * j + kq] : 0.f;
+                d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, B[j], d, 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -320,7 +337,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_feat_kernel(
     pf.issue(tb, n_kept, RS, tid, pf_lines);
 
     // the whole reduction is rank one: every slot goes through the matrix cores (RankOneFold above)
-    RankOneFold<NS, F0, GS, ACC> fold;
+    RankOneFold<NS, F0, GS, ACC, true> fold;
     fold.init(&s_fold[wave], lane, tx, ty, wave, W, H,
               [&](int n, size_t p) { return dL_dcolor[(size_t)(F0 + n) * plane + p]; });
     float T = 1.0f;
