@@ -211,6 +211,112 @@ __global__ __launch_bounds__(kBlock) void kmeans_mfma_pass_kernel(const float* _
     }
 }
 
+// ---- accumulate pass, software pipelined --------------------------------------------------------------------------
+// SQ counters of the plain pass (profiles/r02_kmeans_sq_counters_per_launch.json): 75.7 us of VALU issue (the distance
+// loop, at 100 % of the issue slots) + 26 us of matrix-pipe time (the exact-fp32 one-hot MFMAs, at the f32 MFMA peak),
+// back to back because workgroup barriers separate the two phases.  Here the rows are double-buffered in LDS and the
+// MFMAs of trip t-1 are issued INSIDE the distance loop of trip t -- one group of CB MFMAs after every four centres --
+// so the matrix pipe works under the VALU.  Same points in the same order into the same accumulators: the partial
+// tables are bit-identical to the plain kernel's.  (PPL = 1, compile-time width only.)
+template <int CB, int DT>
+__global__ __launch_bounds__(kBlock) void kmeans_accum_pipelined_kernel(const float* __restrict__ feat, int64_t N,
+                                                                        const float* __restrict__ centers, int k,
+                                                                        int k_active, float* __restrict__ partials) {
+    constexpr int d = DT;
+    constexpr int GROUPS = kWave / 4;                    // MFMA groups (4 points each) per wave and trip
+    extern __shared__ float smem[];
+    float* rows0 = smem;                                 // [2][256*d] staged rows, double buffered
+    int* ids0 = reinterpret_cast<int*>(rows0 + 2 * kBlock * d);   // [2][256] ids of the staged rows (-1: no row)
+    float* wtab = rows0;                                 // epilogue only: per-wave tables reuse the rows region
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    floatx4 acc[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) acc[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const int kq = lane >> 4, j = lane & 15;
+    const int64_t nblk = (N + kBlock - 1) / kBlock;
+    int buf = 0;
+    bool have_prev = false;
+    auto group = [&](const float* __restrict__ prow, const int* __restrict__ pids, int g) {
+        const int p = wave * kWave + g * 4 + kq;
+        const int id = pids[p];
+        float b = 0.f;
+        if (id >= 0) b = j < d ? prow[p * d + j] : (j == d ? 1.0f : 0.f);
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            const float a = (id == cb * 16 + j) ? 1.0f : 0.f;
+            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[cb], 0, 0, 0);
+        }
+    };
+    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        float* rows = rows0 + buf * kBlock * d;
+        int* ids = ids0 + buf * kBlock;
+        const float* prow = rows0 + (buf ^ 1) * kBlock * d;
+        const int* pids = ids0 + (buf ^ 1) * kBlock;
+        const int64_t row0 = blk * kBlock;
+        const int nrows = (int)min((int64_t)kBlock, N - row0);
+        const float* src = feat + row0 * d;
+        for (int i = tid; i < nrows * d; i += kBlock) rows[i] = src[i];
+        __syncthreads();                 // rows staged; the previous trip's ids are visible
+        const int row = min(tid, nrows - 1);
+        float x[DT];
+#pragma unroll
+        for (int jj = 0; jj < DT; ++jj) x[jj] = rows[row * DT + jj];
+        float best = 3.4e38f;
+        int best_id = 0, g = 0;
+        const int kc = k_active & ~3;
+        for (int c0 = 0; c0 < kc; c0 += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float* cc = centers + (c0 + u) * DT;       // wave-uniform: scalar loads, SGPR operands
+                float s = 0.f;
+#pragma unroll
+                for (int jj = 0; jj < DT; ++jj) {
+                    const float t = x[jj] - cc[jj];
+                    s = fmaf(t, t, s);
+                }
+                if (s < best) { best = s; best_id = c0 + u; }
+            }
+            if (have_prev && g < GROUPS) { group(prow, pids, g); ++g; }
+        }
+        for (int c = kc; c < k_active; ++c) {
+            const float* cc = centers + c * DT;
+            float s = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < DT; ++jj) {
+                const float t = x[jj] - cc[jj];
+                s = fmaf(t, t, s);
+            }
+            if (s < best) { best = s; best_id = c; }
+        }
+        if (have_prev)
+            for (; g < GROUPS; ++g) group(prow, pids, g);
+        ids[tid] = tid < nrows ? best_id : -1;
+        __syncthreads();                 // everyone is done with the previous buffers; this trip's ids are written
+        have_prev = true;
+        buf ^= 1;
+    }
+    if (have_prev) {                     // drain: the last trip's points
+        const float* prow = rows0 + (buf ^ 1) * kBlock * d;
+        const int* pids = ids0 + (buf ^ 1) * kBlock;
+        for (int g = 0; g < GROUPS; ++g) group(prow, pids, g);
+    }
+    __syncthreads();                     // wtab aliases the rows
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            wtab[(wave * CB * 16 + cb * 16 + kq * 4 + r) * 16 + j] = acc[cb][r];
+    __syncthreads();
+    float* out = partials + (size_t)blockIdx.x * k * (d + 1);
+    for (int e = tid; e < k * (d + 1); e += kBlock) {
+        const int c = e / (d + 1), col = e - c * (d + 1);
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < kBlock / kWave; ++w) s += wtab[(w * CB * 16 + c) * 16 + col];   // fixed order
+        out[e] = s;
+    }
+}
+
 // ---- fallback for shapes outside the MFMA tiling: per-workgroup LDS accumulators ---------------------------------
 template <bool ACCUM>
 __global__ __launch_bounds__(kBlock) void kmeans_lds_pass_kernel(const float* __restrict__ feat, int64_t N, int d,
@@ -334,6 +440,10 @@ inline int km_ppl() {
     static const int v = [] { const char* e = getenv("OGS_KM_PPL"); return (e && atoi(e) == 2) ? 2 : 1; }();
     return v;
 }
+inline int km_pipelined() {     // OGS_KM_PIPE=0: the plain (phase-separated) accumulate pass
+    static const int v = [] { const char* e = getenv("OGS_KM_PIPE"); return (e && atoi(e) == 0) ? 0 : 1; }();
+    return v;
+}
 inline int km_max_blocks() {
     static const int v = [] { const char* e = getenv("OGS_KM_BLOCKS"); const int n = e ? atoi(e) : 0; return n > 0 ? n : kMaxBlocks; }();
     return v;
@@ -395,6 +505,18 @@ int launch_mfma_p(int nb, hipStream_t s, const float* feat, int64_t N, int d, co
 template <int CB, bool ACCUM, int DT>
 int launch_mfma_d(int nb, hipStream_t s, const float* feat, int64_t N, int d, const float* centers, int k, int k_active,
                   int64_t* ids_out, int64_t id_offset, float* partials) {
+    if constexpr (DT > 0 && ACCUM) {
+        if (km_ppl() == 1 && km_pipelined()) {
+            const size_t rows = (size_t)2 * kBlock * DT + 2 * kBlock, wtab = (size_t)4 * CB * 16 * 16;
+            const size_t lds = sizeof(float) * (rows > wtab ? rows : wtab);
+            int rc = allow_lds(kmeans_accum_pipelined_kernel<CB, DT>, lds);
+            if (rc != OGS_OK) return rc;
+            OGS_LAUNCH_NAMED("kmeans_mfma_pass_kernel<accum>", (kmeans_accum_pipelined_kernel<CB, DT>), dim3(nb), dim3(kBlock), lds,
+                             s, feat, N, centers, k, k_active, partials);
+            OGS_LAUNCH_CHECK(0, s);
+            return OGS_OK;
+        }
+    }
     if constexpr (DT > 0) {
         if (km_ppl() == 2)
             return launch_mfma_p<CB, ACCUM, DT, 2>(nb, s, feat, N, d, centers, k, k_active, ids_out, id_offset, partials);
