@@ -66,6 +66,7 @@ struct RankOneFold {
     uint32_t gidv;  // lane e: Gaussian id of staged entry e
     float B[16];
     int cnt;        // wave-uniform: entries staged
+    bool skip_atomics = false;   // timing experiment (OGS_BLEND_PREFETCH bit 8)
 
     // gmap(n, inside, pix): upstream gradient of channel n at a pixel of image `img`
     template <typename F>
@@ -112,7 +113,7 @@ struct RankOneFold {
             const uint32_t g = (uint32_t)__builtin_amdgcn_ds_bpermute(e * 4, (int)gidv);
             // 32-bit element offset from the (uniform) record array: SGPR-base addressing
             const uint32_t off = g * (uint32_t)GS + (uint32_t)(SLOT0 + m);
-            if (e < cnt && m < NCH) atomicAdd(grad_rec + off, (ACC)d[r]);
+            if (e < cnt && m < NCH && !skip_atomics) atomicAdd(grad_rec + off, (ACC)d[r]);
         }
         cnt = 0;
     }
@@ -144,7 +145,8 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     constexpr int RS = stream_vec4(C) * 4;
     constexpr int GS = grad_stride(C);
     static_assert(C + 7 <= 16, "gradient record must fit 16 slots");
-    constexpr int NCH = C + (DEPTH ? 1 : 0);     // rank-one slots: features (+ depth) -> matrix cores
+    constexpr int NCH = C < 8 ? C : 8;           // features 0..7 -> matrix cores -> the record's first 64-byte half;
+                                                 // feature 8 and depth ride the VALU fold with the geometry (second half)
     __shared__ WaveFoldLds s_fold[kBlock / kWave];
 
     const int tile = blockIdx.x;                // virtual tile (grouped pass): image * tiles + tile in the image
@@ -159,7 +161,6 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     const size_t pix = (size_t)img * plane + (size_t)py * W + px;       // pixel of image `img` in [G,1,H,W] maps
     dL_dcolor += (size_t)img * (C - 1) * plane;                         // + pix: image stride of [G,C,H,W] is C planes
     const float* __restrict__ dcol_img = dL_dcolor + (size_t)img * plane;   // image `img`, indexed by py * W + px
-    const float* __restrict__ ddep_img = DEPTH ? dL_ddepth + (size_t)img * plane : nullptr;
 
     const uint2 range = ranges[tile];
     const int last_contrib = inside ? (int)n_contrib[pix] : 0;
@@ -173,7 +174,8 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     const uint32_t lim = n_kept > 0 ? (uint32_t)n_kept - 1u : 0u;
     auto rec_at = [&](uint32_t i) { return tb + (size_t)(min(i, lim) * (uint32_t)RS); };
     RecordPrefetch pf;
-    pf.issue(tb, n_kept, RS, tid, pf_lines);
+    pf.issue(tb, n_kept, RS, tid, pf_lines & 0xFF);
+    const bool skip_geo = (pf_lines & 0x200) != 0;
 
     const float T_final = inside ? final_T[pix] : 0.f;      // the forward's own value (ImageState::final_T)
     float T = T_final;
@@ -189,9 +191,8 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     // dL/dfeature_c and dL/ddepth of an entry are w * g(pixel): rank one -> RankOneFold (matrix cores); the six
     // geometry slots (mean2D x2, conic x3, opacity) stay on the VALU butterfly, now 8 slots wide
     RankOneFold<NCH, 0, GS, ACC> fold;
-    fold.init(&s_fold[wave], lane, tx, ty, wave, W, H, [&](int n, size_t p) {
-        return (DEPTH && n == C) ? ddep_img[p] : dcol_img[(size_t)(n < C ? n : 0) * plane + p];
-    });
+    fold.skip_atomics = (pf_lines & 0x100) != 0;
+    fold.init(&s_fold[wave], lane, tx, ty, wave, W, H, [&](int n, size_t p) { return dcol_img[(size_t)n * plane + p]; });
     float R[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) R[c] = 0.f;
@@ -255,22 +256,25 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
             const float q = opac * sG;
             const float ppx = (2.f * a2) * dx + b2 * dy;
             const float ppy = (2.f * c2) * dy + b2 * dx;
-            v[0] = (q * halfW) * ppx;
-            v[1] = (q * halfH) * ppy;
+            // the record's second half: slots 8..15 = feature 8, depth, mean2D x2, conic x3, opacity
+            v[0] = C == 9 ? w * g[C == 9 ? 8 : 0] : 0.f;
+            v[1] = DEPTH ? w * gd : 0.f;
+            v[2] = (q * halfW) * ppx;
+            v[3] = (q * halfH) * ppy;
             const float hq = -0.5f * q;
             const float hqdx = hq * dx;
-            v[2] = hqdx * dx;
-            v[3] = hqdx * dy;
-            v[4] = (hq * dy) * dy;
-            v[5] = sG;
-            v[6] = 0.f; v[7] = 0.f;
+            v[4] = hqdx * dx;
+            v[5] = hqdx * dy;
+            v[6] = (hq * dy) * dy;
+            v[7] = sG;
             const float y = wave_fold8(v);
             const uint32_t slot = (uint32_t)lane >> 3;
-            if ((lane & 7) == 0 && slot < 6u) {
+            const bool used = slot >= 2u || (slot == 0u && C == 9) || (slot == 1u && DEPTH);
+            if ((lane & 7) == 0 && used && !skip_geo) {
                 // wave-uniform record base (scalar registers) + a 32-bit lane offset: the atomic takes the
                 // SGPR-base addressing form, no 64-bit VALU address arithmetic per entry
                 const uint32_t gid = __builtin_amdgcn_readfirstlane(__float_as_uint(cur[7]));
-                atomic_add_sbase(grad_rec + ((size_t)gid * GS + (C + 1)), slot * (uint32_t)sizeof(ACC), (ACC)y);
+                atomic_add_sbase(grad_rec + ((size_t)gid * GS + kSlotFeat8), slot * (uint32_t)sizeof(ACC), (ACC)y);
             }
         }
     };
@@ -308,7 +312,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_feat_kernel(
     constexpr int RS = stream_vec4(C) * 4;
     constexpr int GS = grad_stride(C);
     constexpr int NS = C - F0;
-    static_assert(NS >= 1 && NS <= 16, "feature slots");
+    static_assert(NS >= 1 && NS <= 9, "feature slots");
     __shared__ WaveFoldLds s_fold[kBlock / kWave];
 
     const int tile = blockIdx.x;
@@ -334,10 +338,11 @@ __global__ __launch_bounds__(kBlock) void blend_backward_feat_kernel(
     const uint32_t lim = n_kept > 0 ? (uint32_t)n_kept - 1u : 0u;
     auto rec_at = [&](uint32_t i) { return tb + (size_t)(min(i, lim) * (uint32_t)RS); };
     RecordPrefetch pf;
-    pf.issue(tb, n_kept, RS, tid, pf_lines);
+    pf.issue(tb, n_kept, RS, tid, pf_lines & 0xFF);
 
     // the whole reduction is rank one: every slot goes through the matrix cores (RankOneFold above)
-    RankOneFold<NS, F0, GS, ACC, true> fold;
+    RankOneFold<NS, 0, GS, ACC, true> fold;       // channels F0..C-1 -> slots 0..NS-1 (feat-only layout, first half)
+    fold.skip_atomics = (pf_lines & 0x100) != 0;
     fold.init(&s_fold[wave], lane, tx, ty, wave, W, H,
               [&](int n, size_t p) { return dL_dcolor[(size_t)(F0 + n) * plane + p]; });
     float T = 1.0f;

@@ -66,7 +66,8 @@ int ogs::blend_prefetch_lines() {
     static const int v = [] {
         const char* e = getenv("OGS_BLEND_PREFETCH");
         const int n = e ? atoi(e) : kPrefetchMax;
-        return n < 0 ? 0 : (n > kPrefetchMax ? kPrefetchMax : n);
+        const int lines = (n & 0xFF) > kPrefetchMax ? kPrefetchMax : (n & 0xFF);
+        return n < 0 ? 0 : (lines | (n & 0x300));        // bits 8 / 9: timing experiments only (skip the feature / geometry atomics)
     }();
     return v;
 }

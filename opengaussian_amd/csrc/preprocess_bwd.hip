@@ -30,7 +30,8 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
     const int32_t* __restrict__ radii, const uint32_t* __restrict__ clamped_in, const ACC* __restrict__ grad_rec,
     float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
-    float* __restrict__ dL_dscales, float* __restrict__ dL_drotations, float* __restrict__ dL_dsh_rgb) {
+    float* __restrict__ dL_dscales, float* __restrict__ dL_drotations, float* __restrict__ dL_dsh_rgb,
+    int feat_only_layout) {
     constexpr int GS = grad_stride(C);
     const int idx = blockIdx.x * kBlock + threadIdx.x;
     if (idx >= P) return;
@@ -53,21 +54,22 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
             gr[4 * k] = t.x; gr[4 * k + 1] = t.y; gr[4 * k + 2] = t.z; gr[4 * k + 3] = t.w;
         }
     }
-    const float d_depth = gr[C];
-    const float dm2x = gr[C + 1], dm2y = gr[C + 2];
-    const float dconA = gr[C + 3], dconB = gr[C + 4], dconC = gr[C + 5];
+    // record layout: ogs_common.h (features 0..7 | feature 8, depth, mean2D, conic, opacity)
+    const float d_depth = gr[kSlotDepth];
+    const float dm2x = gr[kSlotMean2D], dm2y = gr[kSlotMean2D + 1];
+    const float dconA = gr[kSlotConic], dconB = gr[kSlotConic + 1], dconC = gr[kSlotConic + 2];
 
     if (dL_dmeans2D) {
         dL_dmeans2D[3 * idx + 0] = dm2x;
         dL_dmeans2D[3 * idx + 1] = dm2y;
         dL_dmeans2D[3 * idx + 2] = 0.f;
     }
-    if (dL_dopacity) dL_dopacity[idx] = gr[C + 6];
+    if (dL_dopacity) dL_dopacity[idx] = gr[kSlotOpacity];
     const int coff = shs != nullptr ? 3 : 0;       // fused pass: channels 0..2 belong to SH
     if (dL_dcolors) {
 #pragma unroll
         for (int c = 0; c < C; ++c)
-            if (c >= coff) dL_dcolors[(size_t)idx * (C - coff) + (c - coff)] = gr[c];
+            if (c >= coff) dL_dcolors[(size_t)idx * (C - coff) + (c - coff)] = feat_only_layout ? gr[c - coff] : gr[c];
     }
 
     float dmean[3] = {0.f, 0.f, 0.f};
@@ -306,7 +308,8 @@ int launch_c(const OgsRasterBwdArgs& a, const GeomState& gs, const void* grad_re
                        a.sh_coeffs, a.tanfovx, a.tanfovy, focal_x, focal_y, a.scale_modifier, a.means3D, a.shs, a.scales,
                        a.rotations, a.cov3D_precomp, a.viewmatrix, a.projmatrix, a.campos, a.radii,
                        (const uint32_t*)gs.clamped, (const ACC*)grad_rec, a.dL_dmeans2D, a.dL_dcolors, a.dL_dopacity, a.dL_dmeans3D,
-                       a.dL_dcov3D, a.dL_dsh, a.dL_dscales, a.dL_drotations, a.dL_dsh_rgb);
+                       a.dL_dcov3D, a.dL_dsh, a.dL_dscales, a.dL_drotations, a.dL_dsh_rgb,
+                       backward_is_features_only(a) ? 1 : 0);
     OGS_LAUNCH_CHECK(a.debug, s);
     return OGS_OK;
 }
