@@ -211,6 +211,8 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
         const float dx = cur[0] - fxe, dy = cur[1] - fy;
         const float power = blend_power(a2, b2, c2, dx, dy);
         const bool cand = fabsf(power + cur[5]) <= cur[5];
+        // late entries of a stream find most pixels parked: a wave without a single candidate skips the exp as well
+        if (__ballot(cand) == 0ull) return;
         // All 64 lanes run the same straight-line arithmetic (with the per-quadrant streams nearly every entry
         // has candidates, so a divergent region would save no issue slots, only cost exec-mask SALU ops and a
         // 16-register zero fill): a lane that does not contribute gets alpha = 0 and G = 0, which leaves its
@@ -353,6 +355,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_feat_kernel(
         const float dx = cur[0] - fxe, dy = cur[1] - fy;
         const float power = blend_power(cur[2], cur[3], cur[4], dx, dy);
         const bool cand = fabsf(power + cur[5]) <= cur[5];
+        if (__ballot(cand) == 0ull) return;
         const float alpha = fminf(0.99f, cur[6] * __expf(power));
         const bool act = cand && alpha >= kAlphaMin;
         if (__ballot(act) != 0ull) {
