@@ -317,6 +317,130 @@ __global__ __launch_bounds__(kBlock) void kmeans_accum_pipelined_kernel(const fl
     }
 }
 
+// ---- accumulate pass with the one-hot product on the bf16 matrix path --------------------------------------------
+// The one-hot accumulate  table[id[p]] += [x_p, 1]  is  onehot^T @ rows.  In exact fp32 (v_mfma_f32_16x16x4_f32) it
+// costs N*k*16*2 flops at the f32 MFMA peak = 26 us at N = 2M, k = 64, and that time ADDS to the VALU time of the
+// distance loop (same fp32 datapath).  The one-hot factor is exact in any format and a fp32 row value splits into
+// three bf16 terms hi + mid + lo that carry its 24 significant bits (each residual is exactly representable in
+// fp32), so the same product runs as three v_mfma_f32_16x16x32_bf16 (32 points each, fp32 accumulate) on the
+// 16x faster bf16 path.  Differences to the exact-fp32 table: the rounding of the fp32 accumulation only.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+template <int CB, int DT>
+__global__ __launch_bounds__(kBlock) void kmeans_accum_bf16_kernel(const float* __restrict__ feat, int64_t N,
+                                                                   const float* __restrict__ centers, int k,
+                                                                   int k_active, float* __restrict__ partials) {
+    constexpr int d = DT;
+    constexpr int HALVES = kWave / 32;                   // 32-point MFMA groups per wave and trip
+    extern __shared__ float smem[];
+    float* rows0 = smem;                                 // [2][256*d] staged rows, double buffered
+    int* ids0 = reinterpret_cast<int*>(rows0 + 2 * kBlock * d);   // [2][256] ids of the staged rows (-1: no row)
+    float* wtab = rows0;                                 // epilogue only: per-wave tables reuse the rows region
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    floatx4 acc[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) acc[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const int kq = lane >> 4, j = lane & 15;
+    const int64_t nblk = (N + kBlock - 1) / kBlock;
+    int buf = 0;
+    bool have_prev = false;
+    // lane (kq, j) supplies, for the 8 points p0 .. p0+7 of its k-group: A[m = j][.] = (id == 16 cb + j), B[.][n = j] =
+    // column j of the row -- both operands of a lane refer to the SAME 8 points, which is all the instruction needs
+    auto group32 = [&](const float* __restrict__ prow, const int* __restrict__ pids, int h) {
+        const int p0 = wave * kWave + h * 32 + kq * 8;
+        int id[8];
+        bf16x8_t bh, bm, bl;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            id[i] = pids[p0 + i];
+            float x = 0.f;
+            if (id[i] >= 0) x = j < d ? prow[(p0 + i) * d + j] : (j == d ? 1.0f : 0.f);
+            const __bf16 xh = (__bf16)x;
+            const float r1 = x - (float)xh;
+            const __bf16 xm = (__bf16)r1;
+            const float r2 = r1 - (float)xm;
+            bh[i] = xh; bm[i] = xm; bl[i] = (__bf16)r2;
+        }
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            bf16x8_t a;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] = (id[i] == cb * 16 + j) ? (__bf16)1.0f : (__bf16)0.0f;
+            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bh, acc[cb], 0, 0, 0);
+            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bm, acc[cb], 0, 0, 0);
+            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bl, acc[cb], 0, 0, 0);
+        }
+    };
+    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        float* rows = rows0 + buf * kBlock * d;
+        int* ids = ids0 + buf * kBlock;
+        const float* prow = rows0 + (buf ^ 1) * kBlock * d;
+        const int* pids = ids0 + (buf ^ 1) * kBlock;
+        const int64_t row0 = blk * kBlock;
+        const int nrows = (int)min((int64_t)kBlock, N - row0);
+        const float* src = feat + row0 * d;
+        for (int i = tid; i < nrows * d; i += kBlock) rows[i] = src[i];
+        __syncthreads();                 // rows staged; the previous trip's ids are visible
+        const int row = min(tid, nrows - 1);
+        float x[DT];
+#pragma unroll
+        for (int jj = 0; jj < DT; ++jj) x[jj] = rows[row * DT + jj];
+        float best = 3.4e38f;
+        int best_id = 0, g = 0;
+        const int kc = k_active & ~3;
+        const int trig0 = (kc / 4) / 4 * 4, trig1 = (3 * (kc / 4)) / 4 * 4;     // centre chunks after which a group is issued
+        for (int c0 = 0; c0 < kc; c0 += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float* cc = centers + (c0 + u) * DT;       // wave-uniform: scalar loads, SGPR operands
+                float s = 0.f;
+#pragma unroll
+                for (int jj = 0; jj < DT; ++jj) {
+                    const float t = x[jj] - cc[jj];
+                    s = fmaf(t, t, s);
+                }
+                if (s < best) { best = s; best_id = c0 + u; }
+            }
+            if (have_prev && g < HALVES && (c0 == trig0 || c0 == trig1)) { group32(prow, pids, g); ++g; }
+        }
+        for (int c = kc; c < k_active; ++c) {
+            const float* cc = centers + c * DT;
+            float s = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < DT; ++jj) {
+                const float t = x[jj] - cc[jj];
+                s = fmaf(t, t, s);
+            }
+            if (s < best) { best = s; best_id = c; }
+        }
+        if (have_prev)
+            for (; g < HALVES; ++g) group32(prow, pids, g);
+        ids[tid] = tid < nrows ? best_id : -1;
+        __syncthreads();                 // everyone is done with the previous buffers; this trip's ids are written
+        have_prev = true;
+        buf ^= 1;
+    }
+    if (have_prev) {                     // drain: the last trip's points
+        const float* prow = rows0 + (buf ^ 1) * kBlock * d;
+        const int* pids = ids0 + (buf ^ 1) * kBlock;
+        for (int g = 0; g < HALVES; ++g) group32(prow, pids, g);
+    }
+    __syncthreads();                     // wtab aliases the rows
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            wtab[(wave * CB * 16 + cb * 16 + kq * 4 + r) * 16 + j] = acc[cb][r];
+    __syncthreads();
+    float* out = partials + (size_t)blockIdx.x * k * (d + 1);
+    for (int e = tid; e < k * (d + 1); e += kBlock) {
+        const int c = e / (d + 1), col = e - c * (d + 1);
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < kBlock / kWave; ++w) s += wtab[(w * CB * 16 + c) * 16 + col];   // fixed order
+        out[e] = s;
+    }
+}
+
 // ---- fallback for shapes outside the MFMA tiling: per-workgroup LDS accumulators ---------------------------------
 template <bool ACCUM>
 __global__ __launch_bounds__(kBlock) void kmeans_lds_pass_kernel(const float* __restrict__ feat, int64_t N, int d,
@@ -444,6 +568,10 @@ inline int km_pipelined() {     // OGS_KM_PIPE=0: the plain (phase-separated) ac
     static const int v = [] { const char* e = getenv("OGS_KM_PIPE"); return (e && atoi(e) == 0) ? 0 : 1; }();
     return v;
 }
+inline int km_bf16() {          // OGS_KM_BF16=0: the exact-fp32 one-hot MFMAs
+    static const int v = [] { const char* e = getenv("OGS_KM_BF16"); return (e && atoi(e) == 0) ? 0 : 1; }();
+    return v;
+}
 inline int km_max_blocks() {
     static const int v = [] { const char* e = getenv("OGS_KM_BLOCKS"); const int n = e ? atoi(e) : 0; return n > 0 ? n : kMaxBlocks; }();
     return v;
@@ -509,6 +637,14 @@ int launch_mfma_d(int nb, hipStream_t s, const float* feat, int64_t N, int d, co
         if (km_ppl() == 1 && km_pipelined()) {
             const size_t rows = (size_t)2 * kBlock * DT + 2 * kBlock, wtab = (size_t)4 * CB * 16 * 16;
             const size_t lds = sizeof(float) * (rows > wtab ? rows : wtab);
+            if (km_bf16()) {
+                int rc = allow_lds(kmeans_accum_bf16_kernel<CB, DT>, lds);
+                if (rc != OGS_OK) return rc;
+                OGS_LAUNCH_NAMED("kmeans_mfma_pass_kernel<accum>", (kmeans_accum_bf16_kernel<CB, DT>), dim3(nb), dim3(kBlock), lds,
+                                 s, feat, N, centers, k, k_active, partials);
+                OGS_LAUNCH_CHECK(0, s);
+                return OGS_OK;
+            }
             int rc = allow_lds(kmeans_accum_pipelined_kernel<CB, DT>, lds);
             if (rc != OGS_OK) return rc;
             OGS_LAUNCH_NAMED("kmeans_mfma_pass_kernel<accum>", (kmeans_accum_pipelined_kernel<CB, DT>), dim3(nb), dim3(kBlock), lds,
