@@ -254,11 +254,13 @@ def densify_and_prune(state: DensifyState, max_grad: float, min_opacity: float, 
     if n_out:
         check(lib.ogs_densify_map(N, ptr(tmp), ptr(src_row), ptr(kind), ptr(sample_row), _stream()), "ogs_densify_map")
     if samples is None:
-        # the reference's draw (:443-445): std = scaling of the selected parents, repeated for the two copies
-        # the plan's 4th flag array ("selected for split"); ogs_densify_tmp_bytes carves 256-byte aligned uint32[N] arrays
-        f_sel = tmp[3 * ((4 * N + 255) // 256 * 256):][: 4 * N].view(torch.int32)
-        stds = torch.exp(scaling[f_sel.bool()]).repeat(2, 1)
-        samples = torch.normal(mean=torch.zeros_like(stds), std=stds, generator=generator)
+        # the reference's draw (:443-445): torch.normal(mean=0, std=scaling of the selected parents, repeated for the
+        # two copies).  Only the children that survive the final prune consume their draw, so only those rows are
+        # drawn (row sample_row[r] of the [2S,3] table belongs to child r; the rows of pruned children stay zero)
+        child = kind >= 2
+        stds = torch.exp(scaling[src_row[child].long()])
+        samples = torch.zeros(2 * S, 3, dtype=torch.float32, device=dev)
+        samples[sample_row[child].long()] = torch.normal(mean=torch.zeros_like(stds), std=stds, generator=generator)
     samples = _f32c(samples)
     if samples.shape != (2 * S, 3):
         raise RuntimeError(f"samples must be [2*S,3] with S={S} selected split parents, got {tuple(samples.shape)}")

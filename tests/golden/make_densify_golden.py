@@ -123,7 +123,7 @@ def snapshot(m):
     return out
 
 
-def describe(snap, params0, prefix, store):
+def describe(snap, prefix, store):
     """compact description of a post-operation state (see module docstring)"""
     tag = snap["ins_feat"][0][:, 0]
     src = tag.round().to(torch.int64)
@@ -148,7 +148,7 @@ def main():
             m = build_model(GaussianModel, params, grads)
             m.xyz_gradient_accum, m.denom, m.max_radii2D = accum.clone(), denom.clone(), radii.clone()
             m.prune_points(prune_mask.clone())
-            describe(snapshot(m), params, k + "_prune", store)
+            describe(snapshot(m), k + "_prune", store)
             store[k + "_prune_stats"] = np.concatenate([m.xyz_gradient_accum.numpy().ravel(), m.denom.numpy().ravel(),
                                                        m.max_radii2D.numpy().ravel()])
             # --- B: add_densification_stats + densify_and_prune --------------------------------------------------
@@ -162,7 +162,7 @@ def main():
             m.densify_and_prune(max_grad, 0.005, extent, size_threshold)
             assert len(shim.samples) == 1
             store[k + "_samples"] = shim.samples[0].numpy()
-            describe(snapshot(m), params, k + "_densify", store)
+            describe(snapshot(m), k + "_densify", store)
             assert float(m.xyz_gradient_accum.abs().sum()) == 0 and float(m.max_radii2D.abs().sum()) == 0
             store[k + "_densify_n"] = np.array([m.get_xyz.shape[0], m.denom.shape[0], m.max_radii2D.shape[0]])
             # --- C: reset_opacity ----------------------------------------------------------------------------
