@@ -57,3 +57,95 @@ def test_stage1_iterations_reduce_the_loss_and_only_touch_ins_feat(gpu_device):
     q.forward(g, 1, assign=True, mode="root", pos_weight=0.5)
     assert q.centers.shape == (8, 9) and q.nn_index.shape == (P,) and int(q.nn_index.max()) < 8
     assert g._ins_feat_q.shape == (P, 6) and g._ins_feat_q.requires_grad
+
+
+class _Model:
+    """The slice of scene/gaussian_model.py:GaussianModel a stage-0 iteration touches: raw parameters + activations
+    (:122-169), the seven-group optimizer (:216-230) and the densification state, with the method bodies replaced
+    as INTEGRATION.md section 7b shows."""
+
+    def __init__(self, sc, dev):
+        from opengaussian_amd import densify
+        from opengaussian_amd.optim import FusedAdam
+        P = torch.nn.Parameter
+        self._xyz = P(sc.means3D.to(dev))
+        self._features_dc = P(sc.shs[:, :1].contiguous().to(dev))
+        self._features_rest = P(sc.shs[:, 1:].contiguous().to(dev))
+        self._opacity = P(torch.logit(sc.opacities.clamp(1e-4, 1 - 1e-4)).to(dev))
+        self._scaling = P(torch.log(sc.scales).to(dev))
+        self._rotation = P(sc.rotations.to(dev))
+        self._ins_feat = P((sc.ins_feat * 2 - 1).to(dev))
+        self.active_sh_degree = self.max_sh_degree = 3
+        lrs = {"xyz": 1.6e-4, "f_dc": 2.5e-3, "f_rest": 1.25e-4, "opacity": 0.05, "scaling": 5e-3, "rotation": 1e-3, "ins_feat": 1e-3}
+        self.optimizer = FusedAdam([{"params": [getattr(self, a)], "lr": lrs[n], "name": n} for n, a in self.ATTR.items()],
+                                   lr=0.0, eps=1e-15)
+        n = self._xyz.shape[0]
+        self.state = densify.DensifyState(self.optimizer, torch.zeros(n, 1, device=dev), torch.zeros(n, 1, device=dev),
+                                          torch.zeros(n, device=dev), 0.01)
+
+    ATTR = {"xyz": "_xyz", "f_dc": "_features_dc", "f_rest": "_features_rest", "opacity": "_opacity", "scaling": "_scaling",
+            "rotation": "_rotation", "ins_feat": "_ins_feat"}
+    get_xyz = property(lambda s: s._xyz)
+    get_scaling = property(lambda s: torch.exp(s._scaling))
+    get_rotation = property(lambda s: torch.nn.functional.normalize(s._rotation))
+    get_opacity = property(lambda s: torch.sigmoid(s._opacity))
+    get_features = property(lambda s: torch.cat((s._features_dc, s._features_rest), dim=1))
+
+    def get_ins_feat(self, origin=False):
+        return torch.nn.functional.normalize(self._ins_feat, dim=1)
+
+    def adopt(self, params):
+        for n, a in self.ATTR.items():
+            setattr(self, a, params[n])
+
+
+def test_stage0_iterations_with_densification(gpu_device):
+    """Stage 0 as train.py:352-358,497-498,594-611 wires it: render() -> L1 loss -> backward through the rasterizer
+    (all gradient families) -> max_radii2D / add_densification_stats -> densify_and_prune every few iterations ->
+    FusedAdam over the seven groups.  The pieces must compose: the optimizer state follows the row map, the point
+    count changes between passes (capacity hint, gradient record sizes), the loss keeps going down."""
+    from opengaussian_amd import densify
+    from opengaussian_amd.renderer import render
+    dev = gpu_device
+    W, H, f, P = 160, 112, 120.0, 5000
+    sc, cam = helpers.tiny_scene(P, W, H, f, seed=5, log_scale_mean=-3.0)
+    cam = cam.to(dev)
+    target_sc, _ = helpers.tiny_scene(P, W, H, f, seed=6, log_scale_mean=-3.0)
+    pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=False)
+    bg = torch.zeros(3, device=dev)
+    with torch.no_grad():
+        target = render(cam, _Model(target_sc, dev), pipe, bg, iteration=0, rescale=False, render_feat_map=False)["render"]
+    m = _Model(sc, dev)
+    losses, counts = [], []
+    torch.manual_seed(0)
+    for it in range(1, 25):
+        out = render(cam, m, pipe, bg, iteration=it, rescale=False, render_feat_map=False)
+        loss = (out["render"] - target).abs().mean()
+        m.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        losses.append(float(loss.detach()))
+        counts.append(int(m._xyz.shape[0]))
+        vsp, radii = out["viewspace_points"], out["radii"]
+        assert vsp.grad is not None and vsp.grad.shape == (counts[-1], 3)
+        # train.py:597-598 in one pass: max_radii2D = max(., radii) on visible points, gradient-norm statistics
+        densify.add_densification_stats(m.state, vsp.grad, None, radii)
+        assert float(m.state.denom.max()) >= 1.0 and float(m.state.max_radii2D.max()) >= float(radii.max())
+        if it % 8 == 0:                                       # train.py:600-602
+            thr = float((m.state.xyz_gradient_accum / m.state.denom.clamp_min(1)).quantile(0.9))
+            m.adopt(densify.densify_and_prune(m.state, thr, 0.005, 4.0, 20))
+            plan = m.state.last_plan
+            assert plan["clones"] + plan["split_children"] > 0 and m._xyz.shape[0] == plan["kept"] + plan["clones"] + plan["split_children"]
+            for n, a in m.ATTR.items():                       # the optimizer follows: same tensors, aligned moments
+                p = getattr(m, a)
+                assert m.optimizer.param_groups[list(m.ATTR).index(n)]["params"][0] is p
+                st = m.optimizer.state[p]
+                assert st["exp_avg"].shape == p.shape and st["exp_avg_sq"].shape == p.shape
+        m.optimizer.step()                                    # train.py:608-609 (fresh parameters have no gradient: skipped)
+    assert len(set(counts)) >= 3, counts                       # the point count really changed between passes
+    assert min(losses[-4:]) < losses[0], losses
+    assert all(torch.isfinite(getattr(m, a)).all() for a in m.ATTR.values())
+    m.adopt({**m.state.params(), **densify.reset_opacity(m.state)})          # train.py:604-605
+    assert float(torch.sigmoid(m._opacity).max()) <= 0.01 + 1e-6
+    out = render(cam, m, pipe, bg, iteration=99, rescale=False, render_feat_map=False)
+    out["render"].sum().backward()
+    m.optimizer.step()
