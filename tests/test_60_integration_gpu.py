@@ -138,8 +138,11 @@ def test_stage0_iterations_with_densification(gpu_device):
             for n, a in m.ATTR.items():                       # the optimizer follows: same tensors, aligned moments
                 p = getattr(m, a)
                 assert m.optimizer.param_groups[list(m.ATTR).index(n)]["params"][0] is p
-                st = m.optimizer.state[p]
-                assert st["exp_avg"].shape == p.shape and st["exp_avg_sq"].shape == p.shape
+                st = m.optimizer.state.get(p, {})
+                if n == "ins_feat":                           # never rendered here: no gradient, no Adam state (as in torch)
+                    assert "exp_avg" not in st
+                else:
+                    assert st["exp_avg"].shape == p.shape and st["exp_avg_sq"].shape == p.shape
         m.optimizer.step()                                    # train.py:608-609 (fresh parameters have no gradient: skipped)
     assert len(set(counts)) >= 3, counts                       # the point count really changed between passes
     assert min(losses[-4:]) < losses[0], losses
