@@ -2,18 +2,21 @@
 //
 // One workgroup per 16x16 tile, each wave64 owns an 8x8 quadrant and walks ITS index stream (blend_fwd.hip)
 // BACK-TO-FRONT from its own last contributor, indices and records fetched with wave-uniform scalar loads:
-// no LDS, no barriers.
+// no barriers.
 // Per (pixel, Gaussian) the C+7 partial gradients are NOT sent to memory one float atomic each (the
-// reference's ~10 atomics per pair).  They are reduced over the wave's 64 pixels first, in two ways:
-//   * the C feature slots (+ depth) are rank one in (entry, pixel) -- weight x upstream pixel gradient -- and go
-//     through the MATRIX CORES sixteen entries at a time (RankOneFold below: exact-fp32 16x16x4 MFMAs);
-//   * the six geometry slots (mean2D x2, conic x3, opacity) are folded on the VALU with a transposed butterfly
-//         v_permlane32_swap (xor 32) -> v_permlane16_swap (xor 16) -> DPP row_ror:8 -> quad_perm x2 -> row_half_mirror
-//     (wave_fold8: ~17 VALU for 8 slots; round 1 folded all 16 slots this way, ~35 VALU) so that lane 8*s ends up
-//     with the wave total of slot s.
-// Atomics: one instruction per (Gaussian, wave) for the geometry segment, one per FOUR entries for the feature
-// rows, into the fp64 gradient record.  An entry is skipped for the whole wave when a ballot shows no lane
-// received a contribution.
+// reference's ~10 atomics per pair).  They are reduced over the wave's 64 pixels first, ALL of them on the MATRIX
+// CORES (PairFold below: exact-fp32 16x16x4 MFMAs, eight entries at a time):
+//   * the C feature slots (+ depth) are rank one in (entry, pixel): blend weight x upstream pixel gradient;
+//   * the six geometry slots (mean2D x2, conic x3, opacity) are linear in the six pixel MOMENTS of
+//     q = opacity * G * dL/dalpha -- sum q * {1, u, v, u^2, uv, v^2}, (u, v) the pixel offset from the quadrant centre --
+//     which are rank one as well; a per-entry shift of the moments to the Gaussian's own centre (a handful of VALU
+//     operations per EIGHT entries and lane) makes them independent of the quadrant, and preprocess_bwd.hip applies
+//     the per-Gaussian linear map (conic, opacity) once per Gaussian instead of once per (entry, pixel).
+//   (Round 1 folded all 16 slots with a transposed DPP butterfly, ~35 VALU per entry; round 2 b the feature slots went
+//   to the matrix cores and the geometry slots stayed on an 8-slot butterfly, ~17 VALU + ~14 for the partial products.)
+// Atomics: TWO instructions per eight entries, each lane group of 16 adding one entry's whole 128-byte record,
+// into the fp64 gradient record.  An entry is skipped for the whole wave when a ballot shows no lane received a
+// contribution.
 //
 // `geom_channels` (<= C): only feature channels [0, geom_channels) plus depth and alpha feed dL/dalpha,
 // i.e. the geometry / opacity gradients; channels beyond it only receive their own dL/dfeature.  This is
@@ -126,6 +129,123 @@ struct RankOneFold {
     }
 };
 
+
+// ---- the whole reduction of the full backward on the matrix cores ---------------------------------------------------
+// Eight accepted entries per batch.  Rows of the A matrix: entry e owns row rw(e) = 4 (e / 2) + (e % 2) for its blend
+// weights w_e(p) and row rw(e) + 2 for q_e(p) = opacity * G * dL/dalpha; columns of the B matrix: 0..C-1 the upstream
+// feature gradients g_c(p), 9 the upstream depth gradient, 10..15 the moment basis {1, u, v, u^2, uv, v^2} of pixel p
+// about the quadrant centre.  D = A x B (sixteen 16x16x4 MFMAs, K = the quadrant's 64 pixels):
+//     w rows x columns 0..9   = dL/dfeature_c, dL/ddepth of the entry          (slots 0..9 of the gradient record)
+//     q rows x columns 10..15 = the entry's raw moments M0, Mu, Mv, Muu, Muv, Mvv
+// (the other two blocks are computed and dropped: the matrix pipe has the room, the VALU does not).  With this row
+// order D's register r of lane (column n, lane group k) holds row 4 k + r: registers 0, 1 are w rows and 2, 3 are q
+// rows of entries 2 k, 2 k + 1 -- the moment shift runs on two registers only and ONE atomic instruction per register
+// pair adds four entries' complete records (lane group k = entry, lane n = slot).
+//   shift to the Gaussian's centre (a, b) = centre - quadrant centre, d = centre - pixel = (a - u, b - v):
+//     S0 = M0   Sx = a M0 - Mu   Sy = b M0 - Mv   Sxx = a^2 M0 - 2 a Mu + Muu   Sxy = a b M0 - a Mv - b Mu + Muv   Syy = ...
+//   (u, v in {-3.5 .. 3.5}: every basis value is exact in fp32 and no larger than 12.25, so the raw moments carry no
+//   cancellation of their own; the shift has the conditioning of the direct evaluation sum q d^2).
+// LDS: 16 rows x 68 floats per wave (row stride 68 words: 16-byte aligned rows for the ds_read_b128 of the flush, and
+// the sixteen rows of a lane group land in distinct bank groups).  Gaussian id and centre of the batch's entries live
+// in three VGPRs (entry e in lane e: a select per entry) and are fetched with ds_bpermute.
+constexpr int kPairStride = 68;
+struct PairFoldLds {
+    float t[16 * kPairStride];
+};
+
+template <int N>
+__device__ __forceinline__ float row_bcast(float v) {     // lane n of every row of 16 lanes -> the whole row
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x150 + N, 0xF, 0xF, false));
+}
+
+template <int C, bool DEPTH, int GS, typename ACC>
+struct PairFold {
+    float* t;
+    uint32_t gidv;      // lane e: Gaussian id of staged entry e
+    float mxv, myv;     // lane e: its centre (pixels)
+    float B[16];
+    float x0, y0;       // quadrant centre
+    int cnt;            // wave-uniform: entries staged
+    bool skip_atomics = false;   // timing experiment (OGS_BLEND_PREFETCH bits 8 / 9)
+
+    // gcol(n, pixel): upstream gradient of record slot n (feature n, or depth at slot 9) at a pixel of the image
+    template <typename F>
+    __device__ __forceinline__ void init(PairFoldLds* lds, int lane, int tx, int ty, int wave, int W, int H, F gcol) {
+        t = lds->t;
+        gidv = 0u; mxv = 0.f; myv = 0.f;
+        cnt = 0;
+        x0 = (float)(tx * kTile + (wave & 1) * 8) + 3.5f;
+        y0 = (float)(ty * kTile + (wave >> 1) * 8) + 3.5f;
+        const int n = lane & 15, kq = lane >> 4;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int q = 16 * (j >> 2) + 4 * kq + (j & 3);             // pixel of the 8x8 quadrant fed to MFMA j by this lane group
+            const int px = tx * kTile + (wave & 1) * 8 + (q & 7);
+            const int py = ty * kTile + (wave >> 1) * 8 + (q >> 3);
+            const float u = (float)(q & 7) - 3.5f, v = (float)(q >> 3) - 3.5f;
+            const bool in = px < W && py < H;
+            const bool gcolumn = n < C || (DEPTH && n == kSlotDepth);
+            float b = (in && gcolumn) ? gcol(gcolumn ? n : 0, (size_t)py * W + px) : 0.f;
+            b = n == kSlotMoments ? 1.f : b;
+            b = n == kSlotMoments + 1 ? u : b;
+            b = n == kSlotMoments + 2 ? v : b;
+            b = n == kSlotMoments + 3 ? u * u : b;
+            b = n == kSlotMoments + 4 ? u * v : b;
+            b = n == kSlotMoments + 5 ? v * v : b;
+            B[j] = b;
+        }
+    }
+    __device__ __forceinline__ void flush(ACC* __restrict__ grad_rec, int lane) {
+        const int m = lane & 15, kq = lane >> 4;
+        floatx4 d = {0.f, 0.f, 0.f, 0.f}, d1 = d;
+        // rows beyond the staged entries hold stale weights: a row of A only reaches the same row of D, which is
+        // never written out
+#pragma unroll
+        for (int J = 0; J < 4; ++J) {
+            const float4 a = *reinterpret_cast<const float4*>(t + m * kPairStride + 16 * J + 4 * kq);
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, B[4 * J], d, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, B[4 * J + 1], d1, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, B[4 * J + 2], d, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, B[4 * J + 3], d1, 0, 0, 0);
+        }
+        d = d + d1;
+        const bool column_used = m < C || (DEPTH && m == kSlotDepth) || m >= kSlotMoments;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int e = 2 * kq + rr;
+            const uint32_t g = (uint32_t)__builtin_amdgcn_ds_bpermute(e * 4, (int)gidv);
+            const float a = __int_as_float(__builtin_amdgcn_ds_bpermute(e * 4, __float_as_int(mxv))) - x0;
+            const float b = __int_as_float(__builtin_amdgcn_ds_bpermute(e * 4, __float_as_int(myv))) - y0;
+            const float own = d[2 + rr];
+            const float M0 = row_bcast<kSlotMoments>(own), Mu = row_bcast<kSlotMoments + 1>(own),
+                        Mv = row_bcast<kSlotMoments + 2>(own);
+            const float ta = a * M0, tb = b * M0;
+            float val = own;                                                        // S0
+            val = m == kSlotMoments + 1 ? ta - own : val;                           // Sx
+            val = m == kSlotMoments + 2 ? tb - own : val;                           // Sy
+            val = m == kSlotMoments + 3 ? own + a * (ta - 2.f * Mu) : val;          // Sxx
+            val = m == kSlotMoments + 4 ? (own + a * (tb - Mv)) - b * Mu : val;     // Sxy
+            val = m == kSlotMoments + 5 ? own + b * (tb - 2.f * Mv) : val;          // Syy
+            val = m < kSlotMoments ? d[rr] : val;                                   // feature / depth slots
+            if (e < cnt && column_used && !skip_atomics) atomicAdd(grad_rec + ((size_t)g * GS + m), (ACC)val);
+        }
+        cnt = 0;
+    }
+    // one accepted entry: this lane's blend weight and q, the entry's Gaussian id and centre (wave-uniform)
+    __device__ __forceinline__ void push(float wl, float ql, uint32_t g, float mx, float my, ACC* __restrict__ grad_rec,
+                                         int lane) {
+        float* row = t + (((cnt >> 1) << 2) | (cnt & 1)) * kPairStride;
+        row[lane] = wl;
+        row[2 * kPairStride + lane] = ql;
+        const bool sel = lane == cnt;                  // selects, not a branch
+        gidv = sel ? g : gidv;
+        mxv = sel ? mx : mxv;
+        myv = sel ? my : myv;
+        ++cnt;
+        if (cnt == 8) flush(grad_rec, lane);
+    }
+};
+
 __device__ __forceinline__ int wave_max_i32(int v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, kWave));
@@ -145,9 +265,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     constexpr int RS = stream_vec4(C) * 4;
     constexpr int GS = grad_stride(C);
     static_assert(C + 7 <= 16, "gradient record must fit 16 slots");
-    constexpr int NCH = C < 8 ? C : 8;           // features 0..7 -> matrix cores -> the record's first 64-byte half;
-                                                 // feature 8 and depth ride the VALU fold with the geometry (second half)
-    __shared__ WaveFoldLds s_fold[kBlock / kWave];
+    __shared__ PairFoldLds s_fold[kBlock / kWave];
 
     const int tile = blockIdx.x;                // virtual tile (grouped pass): image * tiles + tile in the image
     const int img = tile / tiles, timg = tile - img * tiles;
@@ -175,29 +293,29 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     auto rec_at = [&](uint32_t i) { return tb + (size_t)(min(i, lim) * (uint32_t)RS); };
     RecordPrefetch pf;
     pf.issue(tb, n_kept, RS, tid, pf_lines & 0xFF);
-    const bool skip_geo = (pf_lines & 0x200) != 0;
 
     const float T_final = inside ? final_T[pix] : 0.f;      // the forward's own value (ImageState::final_T)
     float T = T_final;
-    float g[C];
+    float g[GC];                                           // channels >= GC only appear as columns of the fold's B matrix
     float bg_dot = 0.f;
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
+    for (int c = 0; c < GC; ++c) {
         g[c] = inside ? dL_dcolor[c * plane + pix] : 0.f;
-        if (c < GC) bg_dot += bg[c] * g[c];
+        bg_dot += bg[c] * g[c];
     }
     const float gd = (DEPTH && inside) ? dL_ddepth[pix] : 0.f;
     const float ga = (inside && dL_dalpha_map) ? dL_dalpha_map[pix] : 0.f;
-    // dL/dfeature_c and dL/ddepth of an entry are w * g(pixel): rank one -> RankOneFold (matrix cores); the six
-    // geometry slots (mean2D x2, conic x3, opacity) stay on the VALU butterfly, now 8 slots wide
-    RankOneFold<NCH, 0, GS, ACC> fold;
-    fold.skip_atomics = (pf_lines & 0x100) != 0;
-    fold.init(&s_fold[wave], lane, tx, ty, wave, W, H, [&](int n, size_t p) { return dcol_img[(size_t)n * plane + p]; });
-    float R[C];
+    // every slot of the gradient record is reduced over the quadrant's pixels on the matrix cores (PairFold)
+    PairFold<C, DEPTH, GS, ACC> fold;
+    fold.skip_atomics = (pf_lines & 0x300) != 0;
+    const float* __restrict__ ddepth_img = DEPTH ? dL_ddepth + (size_t)img * plane : nullptr;
+    fold.init(&s_fold[wave], lane, tx, ty, wave, W, H, [&](int n, size_t p) {
+        return (DEPTH && n == kSlotDepth) ? ddepth_img[p] : dcol_img[(size_t)n * plane + p];
+    });
+    float R[GC];
 #pragma unroll
-    for (int c = 0; c < C; ++c) R[c] = 0.f;
+    for (int c = 0; c < GC; ++c) R[c] = 0.f;
     float Rd = 0.f, Ra = 0.f;
-    const float halfW = 0.5f * (float)W, halfH = 0.5f * (float)H;
     const float tf_bg = T_final * bg_dot;                  // loop invariant of the background term
 
     // Same SALU-frugal loop shape as blend_fwd.hip: no break / continue, two ping-pong records (no register
@@ -224,21 +342,17 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
         if (__ballot(act) != 0ull) {
             const float al = act ? alpha : 0.f;
             const float G = act ? Graw : 0.f;
-            float v[8];
             // 1-ulp hardware reciprocal: the correctly rounded 1/x is a ~10-instruction sequence per entry, and the
             // T recursion is dominated by the rounding of the multiply anyway
             const float inv = __builtin_amdgcn_rcpf(1.0f - al);
             T = T * inv;
             const float w = al * T;
             float dL_dalpha = 0.f;
-            fold.push(w, __float_as_uint(cur[7]), grad_rec, lane);     // features (+ depth): matrix cores
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                if (c < GC) {
-                    const float diff = rec_j.feat(c) - R[c];
-                    dL_dalpha += diff * g[c];
-                    R[c] += al * diff;
-                }
+            for (int c = 0; c < GC; ++c) {
+                const float diff = rec_j.feat(c) - R[c];
+                dL_dalpha += diff * g[c];
+                R[c] += al * diff;
             }
             if constexpr (DEPTH) {
                 const float diff = rec_j.feat(C) - Rd;
@@ -251,33 +365,10 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
                 Ra += al * diff;
             }
             dL_dalpha = dL_dalpha * T - inv * tf_bg;
-            // power = a2*dx^2 + c2*dy^2 + b2*dx*dy (a2 = -A/2, c2 = -C/2, b2 = -B):
-            //   dpower/ddx = 2*a2*dx + b2*dy, dpower/ddy = 2*c2*dy + b2*dx, dpower/dA = -dx^2/2, ...
-            // every geometry partial carries the common factor q = opacity * G * dL/dalpha (G = 0 on idle lanes)
-            const float sG = G * dL_dalpha;
-            const float q = opac * sG;
-            const float ppx = (2.f * a2) * dx + b2 * dy;
-            const float ppy = (2.f * c2) * dy + b2 * dx;
-            // the record's second half: slots 8..15 = feature 8, depth, mean2D x2, conic x3, opacity
-            v[0] = C == 9 ? w * g[C == 9 ? 8 : 0] : 0.f;
-            v[1] = DEPTH ? w * gd : 0.f;
-            v[2] = (q * halfW) * ppx;
-            v[3] = (q * halfH) * ppy;
-            const float hq = -0.5f * q;
-            const float hqdx = hq * dx;
-            v[4] = hqdx * dx;
-            v[5] = hqdx * dy;
-            v[6] = (hq * dy) * dy;
-            v[7] = sG;
-            const float y = wave_fold8(v);
-            const uint32_t slot = (uint32_t)lane >> 3;
-            const bool used = slot >= 2u || (slot == 0u && C == 9) || (slot == 1u && DEPTH);
-            if ((lane & 7) == 0 && used && !skip_geo) {
-                // wave-uniform record base (scalar registers) + a 32-bit lane offset: the atomic takes the
-                // SGPR-base addressing form, no 64-bit VALU address arithmetic per entry
-                const uint32_t gid = __builtin_amdgcn_readfirstlane(__float_as_uint(cur[7]));
-                atomic_add_sbase(grad_rec + ((size_t)gid * GS + kSlotFeat8), slot * (uint32_t)sizeof(ACC), (ACC)y);
-            }
+            // every geometry partial carries the common factor q = opacity * G * dL/dalpha (G = 0 on idle lanes) times a
+            // polynomial of the pixel offset: the fold takes q's pixel moments, preprocess_bwd.hip does the rest
+            const float q = opac * (G * dL_dalpha);
+            fold.push(w, q, __float_as_uint(cur[7]), cur[0], cur[1], grad_rec, lane);
         }
     };
     // back-to-front over the quadrant's index stream (see blend_fwd.hip): two records in flight, their indices

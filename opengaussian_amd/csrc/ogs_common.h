@@ -126,14 +126,13 @@ struct StreamRec {
 };
 
 // Per-Gaussian gradient record accumulated by the backward blend: 16 slots (fp64: 128 B = two 64-byte halves, the
-// granularity of the memory-side atomics).  The layout keeps each of the two atomic instructions of an entry inside
-// ONE half -- the backward blend is bound by the rate of those atomic segments (844 MB of atomic traffic per S1M launch
-// when the feature row straddled both halves, against ~1.3 TB/s the memory side sustains):
-//   first half   [0..7]  dL/dfeature 0..7                       (matrix-core reduction, RankOneFold)
-//   second half  [8]     dL/dfeature 8 (C == 9)   [9] dL/ddepth   [10..11] dL/dmean2D (NDC scaled)
-//                [12..14] dL/dconic (A,B,C)       [15] dL/dopacity   (8-slot VALU fold)
+// granularity of the memory-side atomics; one lane group of 16 adds a whole record with one instruction):
+//   [0..8]   dL/dfeature 0..8      [9] dL/ddepth
+//   [10..15] centred pixel moments of q = opacity * G * dL/dalpha: S0, Sx, Sy, Sxx, Sxy, Syy (d = centre - pixel);
+//            preprocess_bwd.hip maps them to dL/dmean2D, dL/dconic, dL/dopacity
+// (blend_bwd.hip: every slot is reduced on the matrix cores).
 // Features-only backward (blend_backward_feat_kernel): channels F0..C-1 sit at slots 0..C-F0-1 (first half only).
-constexpr int kSlotFeat8 = 8, kSlotDepth = 9, kSlotMean2D = 10, kSlotConic = 12, kSlotOpacity = 15;
+constexpr int kSlotDepth = 9, kSlotMoments = 10;
 __host__ __device__ constexpr int grad_stride(int C) { return (C + 7 <= 16) ? 16 : 32; }
 
 // ---- geometry scratch layout (shared by forward phases) ------------------------------------------

@@ -27,7 +27,8 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
     float scale_modifier, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
     const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
-    const int32_t* __restrict__ radii, const uint32_t* __restrict__ clamped_in, const ACC* __restrict__ grad_rec,
+    const int32_t* __restrict__ radii, const uint32_t* __restrict__ clamped_in, const float4* __restrict__ rec,
+    const ACC* __restrict__ grad_rec,
     float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
     float* __restrict__ dL_dscales, float* __restrict__ dL_drotations, float* __restrict__ dL_dsh_rgb,
@@ -54,17 +55,30 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
             gr[4 * k] = t.x; gr[4 * k + 1] = t.y; gr[4 * k + 2] = t.z; gr[4 * k + 3] = t.w;
         }
     }
-    // record layout: ogs_common.h (features 0..7 | feature 8, depth, mean2D, conic, opacity)
+    // record layout: ogs_common.h (features 0..8, depth, then the six centred moments of q = opacity * G * dL/dalpha
+    // over the Gaussian's pixels: S0, Sx, Sy, Sxx, Sxy, Syy with d = centre - pixel).  The per-(entry, pixel) geometry
+    // partials of the reference's backward blend are this linear map of the moments, applied once per Gaussian:
+    //   dL/dmean2D = (W/2, H/2) * sum q * dpower/dd,  dpower/dd = -(A dx + B dy, C dy + B dx)
+    //   dL/dconic  = -1/2 sum q * (dx^2, dx dy, dy^2)          dL/dopacity = sum G dL/dalpha = S0 / opacity
     const float d_depth = gr[kSlotDepth];
-    const float dm2x = gr[kSlotMean2D], dm2y = gr[kSlotMean2D + 1];
-    const float dconA = gr[kSlotConic], dconB = gr[kSlotConic + 1], dconC = gr[kSlotConic + 2];
+    float dm2x = 0.f, dm2y = 0.f, dconA = 0.f, dconB = 0.f, dconC = 0.f, dopac = 0.f;
+    if (vis && !feat_only_layout) {
+        const float4 co = rec[(size_t)idx * rec_vec4(C) + 1];          // conic A, B, C, opacity: what the blend used
+        const float S0 = gr[kSlotMoments], Sx = gr[kSlotMoments + 1], Sy = gr[kSlotMoments + 2];
+        dm2x = (-0.5f * (float)W) * (co.x * Sx + co.y * Sy);
+        dm2y = (-0.5f * (float)H) * (co.z * Sy + co.y * Sx);
+        dconA = -0.5f * gr[kSlotMoments + 3];
+        dconB = -0.5f * gr[kSlotMoments + 4];
+        dconC = -0.5f * gr[kSlotMoments + 5];
+        dopac = co.w > 0.f ? S0 / co.w : 0.f;
+    }
 
     if (dL_dmeans2D) {
         dL_dmeans2D[3 * idx + 0] = dm2x;
         dL_dmeans2D[3 * idx + 1] = dm2y;
         dL_dmeans2D[3 * idx + 2] = 0.f;
     }
-    if (dL_dopacity) dL_dopacity[idx] = gr[kSlotOpacity];
+    if (dL_dopacity) dL_dopacity[idx] = dopac;
     const int coff = shs != nullptr ? 3 : 0;       // fused pass: channels 0..2 belong to SH
     if (dL_dcolors) {
 #pragma unroll
@@ -307,7 +321,7 @@ int launch_c(const OgsRasterBwdArgs& a, const GeomState& gs, const void* grad_re
     OGS_LAUNCH_NAMED(chan_name<C>(kNames), (preprocess_backward_kernel<C, ACC>), dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, a.sh_degree,
                        a.sh_coeffs, a.tanfovx, a.tanfovy, focal_x, focal_y, a.scale_modifier, a.means3D, a.shs, a.scales,
                        a.rotations, a.cov3D_precomp, a.viewmatrix, a.projmatrix, a.campos, a.radii,
-                       (const uint32_t*)gs.clamped, (const ACC*)grad_rec, a.dL_dmeans2D, a.dL_dcolors, a.dL_dopacity, a.dL_dmeans3D,
+                       (const uint32_t*)gs.clamped, (const float4*)gs.rec, (const ACC*)grad_rec, a.dL_dmeans2D, a.dL_dcolors, a.dL_dopacity, a.dL_dmeans3D,
                        a.dL_dcov3D, a.dL_dsh, a.dL_dscales, a.dL_drotations, a.dL_dsh_rgb,
                        backward_is_features_only(a) ? 1 : 0);
     OGS_LAUNCH_CHECK(a.debug, s);

@@ -148,7 +148,7 @@ def test_stage0_iterations_with_densification(gpu_device):
     assert min(losses[-4:]) < losses[0], losses
     assert all(torch.isfinite(getattr(m, a)).all() for a in m.ATTR.values())
     m.adopt({**m.state.params(), **densify.reset_opacity(m.state)})          # train.py:604-605
-    assert float(torch.sigmoid(m._opacity).max()) <= 0.01 + 1e-6
+    assert float(torch.sigmoid(m._opacity.detach()).max()) <= 0.01 + 1e-6
     out = render(cam, m, pipe, bg, iteration=99, rescale=False, render_feat_map=False)
     out["render"].sum().backward()
     m.optimizer.step()
