@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libogs_hip.so")
+# OGS_LIB_PATH: another build of the same library (A-B timing of two kernel versions on one box); never a fallback
+LIB_PATH = os.environ.get("OGS_LIB_PATH") or os.path.join(_HERE, "lib", "libogs_hip.so")
 
 _f32p = C.POINTER(C.c_float)
 _vp = C.c_void_p

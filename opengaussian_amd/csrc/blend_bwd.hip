@@ -237,10 +237,19 @@ struct PairFold {
         float* row = t + (((cnt >> 1) << 2) | (cnt & 1)) * kPairStride;
         row[lane] = wl;
         row[2 * kPairStride + lane] = ql;
-        const bool sel = lane == cnt;                  // selects, not a branch
-        gidv = sel ? g : gidv;
-        mxv = sel ? mx : mxv;
-        myv = sel ? my : myv;
+        // lane cnt of the three stash registers <- wave-uniform values: v_writelane_b32, one instruction each (a select
+        // costs a move of the scalar into a VGPR plus a v_cndmask).  Two different SGPRs in one VOP3 exceed the constant
+        // bus, so the lane select travels in M0 (saved and restored: M0 is the compiler's)
+        uint32_t m0_saved;
+        asm volatile(
+            "s_mov_b32 %3, m0\n\t"
+            "s_mov_b32 m0, %7\n\t"
+            "v_writelane_b32 %0, %4, m0\n\t"
+            "v_writelane_b32 %1, %5, m0\n\t"
+            "v_writelane_b32 %2, %6, m0\n\t"
+            "s_mov_b32 m0, %3"
+            : "+v"(gidv), "+v"(mxv), "+v"(myv), "=&s"(m0_saved)
+            : "s"(g), "s"(mx), "s"(my), "s"(cnt));
         ++cnt;
         if (cnt == 8) flush(grad_rec, lane);
     }
@@ -323,14 +332,17 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     auto consume = [&](const StreamRec<C>& rec_j, int idx) {
         const f8 cur = rec_j.g;
         const float a2 = cur[2], b2 = cur[3], c2 = cur[4];
-        // a pixel whose last contributor lies in front of this entry is parked far away, then ONE compare
-        // |power + h| <= h decides thr <= power <= 0
-        const float fxe = idx < last_contrib ? fx : kFar;
-        const float dx = cur[0] - fxe, dy = cur[1] - fy;
+        // ONE compare |power + h| <= h decides thr <= power <= 0; a pixel whose last contributor lies in front of this
+        // entry is no candidate (a second compare whose mask is ANDed on the scalar side: one VALU operation less than
+        // parking the pixel far away with a select)
+        const float dx = cur[0] - fx, dy = cur[1] - fy;
         const float power = blend_power(a2, b2, c2, dx, dy);
-        const bool cand = fabsf(power + cur[5]) <= cur[5];
-        // late entries of a stream find most pixels parked: a wave without a single candidate skips the exp as well
-        if (__ballot(cand) == 0ull) return;
+        const bool near = fabsf(power + cur[5]) <= cur[5], reached = idx < last_contrib;
+        const bool cand = near && reached;
+        // late entries of a stream find most pixels not reached yet: a wave without a single candidate skips the exp as
+        // well (ballots of single compares ANDed as scalars: the ballot of a compound condition goes through a VGPR)
+        const uint64_t cand_mask = __ballot(near) & __ballot(reached);
+        if (cand_mask == 0ull) return;
         // All 64 lanes run the same straight-line arithmetic (with the per-quadrant streams nearly every entry
         // has candidates, so a divergent region would save no issue slots, only cost exec-mask SALU ops and a
         // 16-register zero fill): a lane that does not contribute gets alpha = 0 and G = 0, which leaves its
@@ -339,7 +351,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
         const float Graw = __expf(power);
         const float alpha = fminf(0.99f, opac * Graw);
         const bool act = cand && alpha >= kAlphaMin;
-        if (__ballot(act) != 0ull) {
+        if ((__ballot(alpha >= kAlphaMin) & cand_mask) != 0ull) {   // scalar AND of two masks (a ballot of `act` goes through a VGPR)
             const float al = act ? alpha : 0.f;
             const float G = act ? Graw : 0.f;
             // 1-ulp hardware reciprocal: the correctly rounded 1/x is a ~10-instruction sequence per entry, and the
@@ -442,14 +454,15 @@ __global__ __launch_bounds__(kBlock) void blend_backward_feat_kernel(
 
     auto consume = [&](const StreamRec<C>& rec_j, int idx) {
         const f8 cur = rec_j.g;
-        const float fxe = idx < last_contrib ? fx : kFar;           // pixels past their last contributor are parked
-        const float dx = cur[0] - fxe, dy = cur[1] - fy;
+        const float dx = cur[0] - fx, dy = cur[1] - fy;
         const float power = blend_power(cur[2], cur[3], cur[4], dx, dy);
-        const bool cand = fabsf(power + cur[5]) <= cur[5];
-        if (__ballot(cand) == 0ull) return;
+        const bool near = fabsf(power + cur[5]) <= cur[5], reached = idx < last_contrib;   // pixels past their last contributor: no
+        const bool cand = near && reached;
+        const uint64_t cand_mask = __ballot(near) & __ballot(reached);
+        if (cand_mask == 0ull) return;
         const float alpha = fminf(0.99f, cur[6] * __expf(power));
         const bool act = cand && alpha >= kAlphaMin;
-        if (__ballot(act) != 0ull) {
+        if ((__ballot(alpha >= kAlphaMin) & cand_mask) != 0ull) {
             const float al = act ? alpha : 0.f;
             const float w = al * T;
             T = T * (1.0f - al);
