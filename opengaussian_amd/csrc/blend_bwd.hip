@@ -270,13 +270,13 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     const uint2* __restrict__ ranges, const float* __restrict__ stream, const uint32_t* __restrict__ quad_list, int W,
     int H, int gx, int tiles, const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const uint32_t* __restrict__ qcount, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha_map,
-    ACC* __restrict__ grad_rec, int pf_lines) {
+    ACC* __restrict__ grad_rec, int pf_lines, const uint32_t* __restrict__ tile_order) {
     constexpr int RS = stream_vec4(C) * 4;
     constexpr int GS = grad_stride(C);
     static_assert(C + 7 <= 16, "gradient record must fit 16 slots");
     __shared__ PairFoldLds s_fold[kBlock / kWave];
 
-    const int tile = blockIdx.x;                // virtual tile (grouped pass): image * tiles + tile in the image
+    const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;                // virtual tile (grouped pass): image * tiles + tile in the image
     const int img = tile / tiles, timg = tile - img * tiles;
     const int tx = timg % gx, ty = timg / gx;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -413,14 +413,14 @@ template <int C, int F0, typename ACC>
 __global__ __launch_bounds__(kBlock) void blend_backward_feat_kernel(
     const uint2* __restrict__ ranges, const float* __restrict__ stream, const uint32_t* __restrict__ quad_list, int W,
     int H, int gx, int tiles, const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ qcount,
-    const float* __restrict__ dL_dcolor, ACC* __restrict__ grad_rec, int pf_lines) {
+    const float* __restrict__ dL_dcolor, ACC* __restrict__ grad_rec, int pf_lines, const uint32_t* __restrict__ tile_order) {
     constexpr int RS = stream_vec4(C) * 4;
     constexpr int GS = grad_stride(C);
     constexpr int NS = C - F0;
     static_assert(NS >= 1 && NS <= 9, "feature slots");
     __shared__ WaveFoldLds s_fold[kBlock / kWave];
 
-    const int tile = blockIdx.x;
+    const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
     const int img = tile / tiles, timg = tile - img * tiles;
     const int tx = timg % gx, ty = timg / gx;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -517,12 +517,13 @@ int launch_c(const OgsRasterBwdArgs& a, const ImageState& is, void* grad_rec_, h
     const float* stream = (const float*)stream_base<C>(const_cast<void*>(a.sorted_rec));
     const uint32_t* quads = quad_base(const_cast<void*>(a.quad_list));
     const unsigned vtiles = (unsigned)(gx * gy) * (unsigned)num_groups_of(a.num_groups);
+    const uint32_t* order = tile_order_of(is, vtiles);          // the forward's heaviest-first order (blend_fwd.hip)
     if (backward_is_features_only(a)) {
         // only dL/dcolors_precomp is owed (stages >= 1, train.py:431-436): no alpha recursion, no geometry partials
 #define OGS_BWD_FEAT(F0V)                                                                                             \
     OGS_LAUNCH_NAMED(chan_name<C>(kFeatNames), (blend_backward_feat_kernel<C, F0V, ACC>), dim3(vtiles), dim3(kBlock), 0, \
                      s, (const uint2*)is.ranges, stream, quads, a.W, a.H, gx, gx * gy, (const uint32_t*)is.n_contrib,    \
-                     (const uint32_t*)is.qcount, a.dL_dcolor, grad_rec, blend_prefetch_lines())
+                     (const uint32_t*)is.qcount, a.dL_dcolor, grad_rec, blend_prefetch_lines(), order)
         if constexpr (C > 3) {
             if (a.shs != nullptr) OGS_BWD_FEAT(3); else OGS_BWD_FEAT(0);
         } else {
@@ -536,7 +537,7 @@ int launch_c(const OgsRasterBwdArgs& a, const ImageState& is, void* grad_rec_, h
     OGS_LAUNCH_NAMED(chan_name<C>(kNames), (blend_backward_kernel<C, GCV, DEPTHV, ACC>), dim3(vtiles), dim3(kBlock), 0, s, \
                      (const uint2*)is.ranges, stream, quads, a.W, a.H, gx, gx * gy, a.bg, (const float*)is.final_T,                  \
                      (const uint32_t*)is.n_contrib, (const uint32_t*)is.qcount, a.dL_dcolor, a.dL_ddepth, a.dL_dalpha, grad_rec,  \
-                     blend_prefetch_lines())
+                     blend_prefetch_lines(), order)
     const bool depth = a.dL_ddepth != nullptr;
     if (a.geom_channels <= 0 || a.geom_channels >= C) {
         if (depth) OGS_BWD_LAUNCH(C, true); else OGS_BWD_LAUNCH(C, false);

@@ -64,11 +64,12 @@ __global__ __launch_bounds__(kBlock) void pack_sorted_kernel(const uint2* __rest
                                                              int tiles, const float4* __restrict__ rec,
                                                              float4* __restrict__ stream,
                                                              uint32_t* __restrict__ quad_list,
-                                                             uint32_t* __restrict__ qcount) {
+                                                             uint32_t* __restrict__ qcount,
+                                                             const uint32_t* __restrict__ tile_order) {
     constexpr int NV = rec_vec4(C);
     constexpr int SV = stream_vec4(C);
     __shared__ uint64_t wave_tot[kBlock / kWave];
-    const int tile = blockIdx.x;                           // virtual tile: image (group) * tiles + tile in the image
+    const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;   // virtual tile: image (group) * tiles + tile in the image
     const int timg = tile % tiles;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint2 range = ranges[tile];
@@ -166,9 +167,9 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ qcount, const float* __restrict__ stream,
     const uint32_t* __restrict__ quad_list, int W, int H, int gx, int tiles, const float* __restrict__ bg, float* __restrict__ out_color,
     float* __restrict__ out_depth, float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib,
-    float* __restrict__ final_T, int pf_lines) {
+    float* __restrict__ final_T, int pf_lines, const uint32_t* __restrict__ tile_order) {
     constexpr int RS = stream_vec4(C) * 4;      // floats per stream record
-    const int tile = blockIdx.x;                // virtual tile (grouped pass): image * tiles + tile in the image
+    const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;   // virtual tile (grouped pass): image * tiles + tile in the image
     const int img = tile / tiles, timg = tile - img * tiles;
     const int tx = timg % gx, ty = timg / gx;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -425,17 +426,96 @@ int tiny_c(const OgsRasterFwdArgs& a, const GeomState& gs, const uint32_t* order
     return OGS_OK;
 }
 
+
+// ---- heaviest-first workgroup order ---------------------------------------------------------------------------------
+// A tile's kernels run as long as its list is long, and the lists of one view span two orders of magnitude.  The
+// hardware hands workgroups to the CUs in index order, so with workgroup = tile in raster order the launch ends with
+// whatever long lists happen to sit at the bottom of the image running alone (SQ counters of the forward blend: 4.4
+// waves per SIMD on average where 8 fit).  One workgroup sorts the tiles by list length into 256 classes of a
+// pseudo-logarithmic scale (3 mantissa bits: classes are <= 12.5 % wide), heaviest class first; order inside a class is
+// whatever the LDS atomics give -- any permutation is a valid schedule.
+constexpr int kOrderThreads = 1024;
+constexpr int64_t kOrderMaxTiles = 1 << 16;      // one workgroup walks all tiles: beyond this the launch costs more than it buys
+__device__ __forceinline__ uint32_t work_class(uint32_t n) {      // 255 = empty ... 0 = longest
+    if (n < 8u) return 255u - n;
+    const uint32_t e = 31u - (uint32_t)__builtin_clz(n);
+    const uint32_t v = e * 8u + ((n >> (e - 3u)) & 7u);          // monotonic in n, 24 .. 255
+    return 255u - min(v, 255u);
+}
+__global__ __launch_bounds__(kOrderThreads) void tile_order_kernel(const uint2* __restrict__ ranges, uint32_t vtiles,
+                                                                   uint32_t* __restrict__ order) {
+    __shared__ uint32_t bins[256];
+    __shared__ uint32_t wave_max[kOrderThreads / kWave], wave_sum[kOrderThreads / kWave];
+    const uint32_t tid = threadIdx.x;
+    // longest list and total length: every thread's loads in flight at once, one LDS slot per wave
+    uint32_t my_max = 0u, my_sum = 0u;
+    for (uint32_t t0 = 0; t0 < vtiles; t0 += 8u * kOrderThreads) {
+        uint2 r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t t = t0 + (uint32_t)k * kOrderThreads + tid;
+            r[k] = t < vtiles ? ranges[t] : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { my_max = max(my_max, r[k].y - r[k].x); my_sum += r[k].y - r[k].x; }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        my_max = max(my_max, (uint32_t)__shfl_xor((int)my_max, d, kWave));
+        my_sum += (uint32_t)__shfl_xor((int)my_sum, d, kWave);
+    }
+    if ((tid & 63u) == 0u) { wave_max[tid >> 6] = my_max; wave_sum[tid >> 6] = my_sum; }
+    if (tid < 256u) bins[tid] = 0u;
+    __syncthreads();
+    uint32_t longest = 0u;
+    unsigned long long total = 0ull;
+#pragma unroll
+    for (int w = 0; w < kOrderThreads / kWave; ++w) { longest = max(longest, wave_max[w]); total += wave_sum[w]; }
+    // lists of similar length everywhere (longest <= 2 x mean): raster order, which keeps neighbouring tiles -- and the
+    // Gaussians they share -- on the chip at the same time (the uniform bench scene: 1.5 % faster forward than a
+    // shuffled order)
+    if ((unsigned long long)longest * vtiles <= 2ull * total) {
+        for (uint32_t t = tid; t < vtiles; t += kOrderThreads) order[t] = t;
+        return;
+    }
+    for (uint32_t t = tid; t < vtiles; t += kOrderThreads) {
+        const uint2 r = ranges[t];
+        atomicAdd(&bins[work_class(r.y - r.x)], 1u);
+    }
+    __syncthreads();
+    if (tid < 64u) {                                      // exclusive scan of the 256 class counts: 4 per lane of one wave
+        uint32_t c[4], sum = 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { c[k] = bins[tid * 4u + k]; sum += c[k]; }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d, kWave);
+            if ((int)tid >= d) incl += o;
+        }
+        uint32_t base = incl - sum;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { bins[tid * 4u + k] = base; base += c[k]; }
+    }
+    __syncthreads();
+    for (uint32_t t = tid; t < vtiles; t += kOrderThreads) {
+        const uint2 r = ranges[t];
+        order[atomicAdd(&bins[work_class(r.y - r.x)], 1u)] = t;
+    }
+}
+
 template <int C>
 int launch_c(const OgsRasterFwdArgs& a, const GeomState& gs, const ImageState& is, int64_t D, hipStream_t s) {
     const int gx = (a.W + kTile - 1) / kTile, gy = (a.H + kTile - 1) / kTile;
     const int tiles = gx * gy;
     const unsigned vtiles = (unsigned)tiles * (unsigned)num_groups_of(a.num_groups);
+    const uint32_t* order = D > 0 ? launch_tile_order(is, vtiles, s, a.debug) : nullptr;
     if (D > 0) {
         static constexpr const char* const kPack[4] = {"pack_sorted_kernel<3>", "pack_sorted_kernel<6>",
                                                        "pack_sorted_kernel<9>", "pack_sorted_kernel<12>"};
         OGS_LAUNCH_NAMED(chan_name<C>(kPack), pack_sorted_kernel<C>, dim3(vtiles), dim3(kBlock), 0, s,
                          (const uint2*)is.ranges, (const uint32_t*)a.point_list, gx, tiles, (const float4*)gs.rec,
-                         stream_base<C>(a.sorted_rec), quad_base(a.quad_list), is.qcount);
+                         stream_base<C>(a.sorted_rec), quad_base(a.quad_list), is.qcount, order);
         OGS_LAUNCH_CHECK(a.debug, s);
     } else {
         OGS_HIP_CHECK(hipMemsetAsync(is.qcount, 0, (size_t)vtiles * 5 * sizeof(uint32_t), s));
@@ -445,7 +525,7 @@ int launch_c(const OgsRasterFwdArgs& a, const GeomState& gs, const ImageState& i
     OGS_LAUNCH_NAMED(chan_name<C>(kNames), blend_forward_kernel<C>, dim3(vtiles), dim3(kBlock), 0, s,
                      (const uint2*)is.ranges, (const uint32_t*)is.qcount, (const float*)stream_base<C>(a.sorted_rec),
                      (const uint32_t*)quad_base(a.quad_list), a.W, a.H, gx, tiles, a.bg, a.out_color, a.out_depth,
-                     a.out_alpha, is.n_contrib, is.final_T, blend_prefetch_lines());
+                     a.out_alpha, is.n_contrib, is.final_T, blend_prefetch_lines(), order);
     OGS_LAUNCH_CHECK(a.debug, s);
     return OGS_OK;
 }
@@ -461,6 +541,21 @@ int export_c(const OgsRasterFwdArgs& a, const ImageState& is, uint32_t* out, hip
 }
 
 }  // namespace
+
+static bool tile_order_enabled() {
+    static const bool v = [] { const char* e = getenv("OGS_TILE_ORDER"); return !(e && atoi(e) == 0); }();
+    return v;
+}
+const uint32_t* tile_order_of(const ImageState& is, int64_t vtiles) {
+    return (tile_order_enabled() && vtiles > 1 && vtiles <= kOrderMaxTiles) ? is.tile_order : nullptr;
+}
+const uint32_t* launch_tile_order(const ImageState& is, int64_t vtiles, hipStream_t s, int debug) {
+    const uint32_t* order = tile_order_of(is, vtiles);
+    if (!order) return nullptr;
+    OGS_LAUNCH(tile_order_kernel, dim3(1), dim3(kOrderThreads), 0, s, (const uint2*)is.ranges, (uint32_t)vtiles, is.tile_order);
+    if (debug) (void)hipStreamSynchronize(s);
+    return order;
+}
 
 int launch_blend_forward(const OgsRasterFwdArgs& a, const GeomState& gs, const ImageState& is, int64_t D,
                          hipStream_t s) {

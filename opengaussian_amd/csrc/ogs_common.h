@@ -162,6 +162,9 @@ struct ImageState {     // kept until backward
                             // The upstream backward re-derives it as 1 - out_alpha (Appendix A.4), which in fp32 loses
                             // up to eps / T_final = 6e-4 relative on saturated pixels (T_final -> 1e-4) and scales every
                             // gradient of the pixel by that error; keeping the forward's own value costs 4 B/pixel.
+    uint32_t* tile_order;   // [tiles] virtual tiles, heaviest list first: workgroup b of the pack / blend kernels takes tile
+                            // tile_order[b] (launch_tile_order; the hardware hands workgroups out in index order, so the
+                            // long lists start first and the short ones fill the tail of the launch)
     // G images of a grouped pass are G * tiles "virtual tiles": virtual tile vt = g * tiles + t
     static ImageState carve(void* p, int W, int H, int G = 1) {
         Carver c(p);
@@ -171,6 +174,7 @@ struct ImageState {     // kept until backward
         s.n_contrib = c.take<uint32_t>((size_t)G * W * H);
         s.qcount = c.take<uint32_t>(tiles * 5);
         s.final_T = c.take<float>((size_t)G * W * H);
+        s.tile_order = c.take<uint32_t>(tiles);
         return s;
     }
     static size_t bytes(int W, int H, int G = 1) {
@@ -180,9 +184,14 @@ struct ImageState {     // kept until backward
         c.take<uint32_t>((size_t)G * W * H);
         c.take<uint32_t>(tiles * 5);
         c.take<float>((size_t)G * W * H);
+        c.take<uint32_t>(tiles);
         return c.off;
     }
 };
+// heaviest-first workgroup order of the per-tile kernels; returns the array the kernels index with blockIdx.x, or
+// nullptr (identity) when the ordering is off (OGS_TILE_ORDER=0) or not worth a launch
+const uint32_t* launch_tile_order(const ImageState& is, int64_t vtiles, hipStream_t s, int debug);
+const uint32_t* tile_order_of(const ImageState& is, int64_t vtiles);      // what the forward of this pass used
 int launch_export_n_contrib(const OgsRasterFwdArgs& a, const ImageState& is, uint32_t* out, hipStream_t s);
 
 // radix sort / scan (binning.hip) ---------------------------------------------------------------

@@ -3,9 +3,15 @@ between consecutive dispatches and which kernels they follow.  usage: python scr
 import collections
 import glob
 import json
+import re
 import os
 import sqlite3
 import sys
+
+
+def short(n):
+    m = re.search(r"(\w+_kernel\w*|__amd_rocclr_\w+|at::native::\w+)", n)
+    return m.group(1) if m else n[:40]
 
 
 def main():
@@ -25,10 +31,15 @@ def main():
     gaps = collections.defaultdict(lambda: [0, 0])
     for (n0, s0, e0), (n1, s1, e1) in zip(seg, seg[1:]):
         g = max(s1 - e0, 0)
-        k = (n0.split("(")[0][-40:], n1.split("(")[0][-40:])
+        k = (short(n0), short(n1))
         gaps[k][0] += g
         gaps[k][1] += 1
-    out = {"columns": cols, "steps": nsteps, "dispatches_per_step": len(seg) / nsteps, "span_ms_per_step": span / nsteps / 1e6,
+    per = collections.defaultdict(lambda: [0, 0])
+    for n, s0, e0 in seg:
+        per[short(n)][0] += e0 - s0
+        per[short(n)][1] += 1
+    out = {"kernel_us_per_step": {k: round(v[0] / nsteps / 1e3, 2) for k, v in sorted(per.items(), key=lambda kv: -kv[1][0])},
+           "steps": nsteps, "dispatches_per_step": len(seg) / nsteps, "span_ms_per_step": span / nsteps / 1e6,
            "busy_ms_per_step": busy / nsteps / 1e6, "idle_ms_per_step": (span - busy) / nsteps / 1e6,
            "largest_gaps_us_per_step": [
                {"after": k[0], "before": k[1], "us_per_step": v[0] / nsteps / 1e3, "count_per_step": v[1] / nsteps}
