@@ -34,9 +34,22 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
     float* __restrict__ dL_dscales, float* __restrict__ dL_drotations, float* __restrict__ dL_dsh_rgb,
     int feat_only_layout) {
     constexpr int GS = grad_stride(C);
-    const int idx = blockIdx.x * kBlock + threadIdx.x;
-    if (idx >= P) return;
-    const bool vis = radii[idx] > 0;
+    // dense dL/dsh = (SH basis of the view direction) x (dL/dRGB): 16 + 3 factors per Gaussian staged here, the 48
+    // products written by the whole workgroup as ONE contiguous range (a thread storing its own 192-byte row makes every
+    // store instruction touch 64 different cache lines)
+    __shared__ float s_basis[kBlock][17];
+    __shared__ float s_drgb[kBlock][3];
+    const int tid = threadIdx.x;
+    const int idx_raw = blockIdx.x * kBlock + tid;
+    const bool valid = idx_raw < P;                 // no early return: the workgroup meets again for the dL/dsh rows
+    const int idx = valid ? idx_raw : P - 1;
+    const bool vis = valid && radii[idx] > 0;
+    const bool dense_sh = dL_dsh != nullptr && shs != nullptr;
+    if (dense_sh) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s_basis[tid][k] = 0.f;
+        s_drgb[tid][0] = 0.f; s_drgb[tid][1] = 0.f; s_drgb[tid][2] = 0.f;
+    }
 
     float gr[16];
     if constexpr (sizeof(ACC) == 8) {
@@ -73,14 +86,14 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
         dopac = co.w > 0.f ? S0 / co.w : 0.f;
     }
 
-    if (dL_dmeans2D) {
+    if (dL_dmeans2D && valid) {
         dL_dmeans2D[3 * idx + 0] = dm2x;
         dL_dmeans2D[3 * idx + 1] = dm2y;
         dL_dmeans2D[3 * idx + 2] = 0.f;
     }
-    if (dL_dopacity) dL_dopacity[idx] = dopac;
+    if (dL_dopacity && valid) dL_dopacity[idx] = dopac;
     const int coff = shs != nullptr ? 3 : 0;       // fused pass: channels 0..2 belong to SH
-    if (dL_dcolors) {
+    if (dL_dcolors && valid) {
 #pragma unroll
         for (int c = 0; c < C; ++c)
             if (c >= coff) dL_dcolors[(size_t)idx * (C - coff) + (c - coff)] = feat_only_layout ? gr[c - coff] : gr[c];
@@ -206,16 +219,16 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
                 const float dRGB[3] = {(cl & 1u) ? 0.f : gr[0], (cl & 2u) ? 0.f : gr[1], (cl & 4u) ? 0.f : gr[2]};
                 drgb_out[0] = dRGB[0]; drgb_out[1] = dRGB[1]; drgb_out[2] = dRGB[2];
                 const float* sh = shs + (size_t)idx * sh_coeffs * 3;
-                float* dsh = dL_dsh + (size_t)idx * sh_coeffs * 3;
                 const float ox = x - campos[0], oy = y - campos[1], oz = z - campos[2];
                 const float il = rsqrtf(ox * ox + oy * oy + oz * oz);
                 const float dxn = ox * il, dyn = oy * il, dzn = oz * il;
                 float ddir[3] = {0.f, 0.f, 0.f};   // dL/d(normalised dir)
+                if constexpr (kWrite) { s_drgb[tid][0] = dRGB[0]; s_drgb[tid][1] = dRGB[1]; s_drgb[tid][2] = dRGB[2]; }
                 auto emit = [&](int k, float basis, float bx, float by, float bz) {
-                    // basis value -> dL/dsh[k]; basis gradient (bx,by,bz) * sh[k] -> dL/ddir
+                    // basis value -> dL/dsh[k] (written below by the whole workgroup); basis gradient (bx,by,bz) * sh[k] -> dL/ddir
+                    if constexpr (kWrite) s_basis[tid][k] = basis;
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch) {
-                        if constexpr (kWrite) dsh[3 * k + ch] = basis * dRGB[ch];
                         const float s = sh[3 * k + ch] * dRGB[ch];
                         ddir[0] += bx * s; ddir[1] += by * s; ddir[2] += bz * s;
                     }
@@ -246,10 +259,6 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
                             emit(15, kC3[6] * dxn * (xx - 3.f * yy), kC3[6] * (3.f * xx - 3.f * yy), kC3[6] * -6.f * xy, 0.f);
                         }
                     }
-                }
-                if constexpr (kWrite) {
-                    const int used = (sh_degree + 1) * (sh_degree + 1);
-                    for (int k = used; k < sh_coeffs; ++k) { dsh[3 * k] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f; }
                 }
                 // d(dir/|dir|)/d(dir) = (I - n n^T) / |dir|
                 const float nd = dxn * ddir[0] + dyn * ddir[1] + dzn * ddir[2];
@@ -289,11 +298,32 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
             drot[3] = 2.f * (-2.f * qz * dR[0] - qr * dR[1] + qx * dR[2] + qr * dR[3] - 2.f * qz * dR[4] + qy * dR[5] +
                              qx * dR[6] + qy * dR[7]);
         }
-    } else if (dL_dsh != nullptr && shs != nullptr) {
-        float* dsh = dL_dsh + (size_t)idx * sh_coeffs * 3;
-        for (int k = 0; k < sh_coeffs * 3; ++k) dsh[k] = 0.f;
     }
 
+    if (dense_sh) {
+        // rows of the workgroup's Gaussians: kBlock * L contiguous floats, element e -> Gaussian e / L, coefficient
+        // (e % L) / 3, channel (e % L) % 3; the same single multiply as before (bit-identical), unused coefficients,
+        // culled Gaussians and a pass that needs no SH gradient get the zeros staged above
+        __syncthreads();
+        const int L = sh_coeffs * 3;
+        const size_t row0 = (size_t)blockIdx.x * kBlock;
+        const int rows = min(kBlock, P - (int)row0);
+        float* __restrict__ out = dL_dsh + row0 * L;
+        auto value = [&](int e) {
+            const int g = e / L, i = e - g * L, k = i / 3, ch = i - 3 * k;
+            return k < 16 ? s_basis[g][k] * s_drgb[g][ch] : 0.f;
+        };
+        if ((L & 3) == 0) {
+            const int n4 = rows * L / 4;
+            for (int e4 = tid; e4 < n4; e4 += kBlock)
+                reinterpret_cast<float4*>(out)[e4] = make_float4(value(4 * e4), value(4 * e4 + 1), value(4 * e4 + 2), value(4 * e4 + 3));
+        } else {
+            const int n = rows * L;
+            for (int e = tid; e < n; e += kBlock) out[e] = value(e);
+        }
+    }
+
+    if (!valid) return;
     if (dL_dsh_rgb) {
         dL_dsh_rgb[3 * idx] = drgb_out[0]; dL_dsh_rgb[3 * idx + 1] = drgb_out[1]; dL_dsh_rgb[3 * idx + 2] = drgb_out[2];
     }
