@@ -98,9 +98,10 @@ __device__ __forceinline__ uint32_t preprocess_one(
     float scale_modifier, const float* __restrict__ means3D, const float* __restrict__ colors_precomp,
     const float* __restrict__ shs, const float* __restrict__ opacities, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix,
-    const float* __restrict__ projmatrix, const float* __restrict__ campos, float4* __restrict__ rec,
+    const float* __restrict__ projmatrix, const float* __restrict__ campos, float4* __restrict__ rec_row,
     uint32_t* __restrict__ clamped_out, int32_t* __restrict__ radii, uint32_t* __restrict__ tiles_touched,
     const int32_t* __restrict__ group_ids, int num_groups) {
+    // rec_row: where this Gaussian's record goes (its row of the record array, or of the workgroup's LDS staging tile)
     constexpr int NV = rec_vec4(C);
     // camera matrices: wave-uniform addresses -> scalar loads
     float V[16], M[16];
@@ -226,7 +227,7 @@ __device__ __forceinline__ uint32_t preprocess_one(
     if (!ok) { pxl = 0.f; pyl = 0.f; cA = cB = cC = 0.f; depth = 0.f; }
 
     // 10. store
-    float4* r = rec + (size_t)idx * NV;
+    float4* r = rec_row;
     r[0] = make_float4(pxl, pyl, depth, __int_as_float(radius));
     r[1] = make_float4(cA, cB, cC, opacity);
 #pragma unroll
@@ -247,12 +248,24 @@ __global__ __launch_bounds__(kBlock) void preprocess_kernel(
     uint32_t* __restrict__ clamped_out, int32_t* __restrict__ radii, uint32_t* __restrict__ tiles_touched,
     uint32_t* __restrict__ depth_keys, uint32_t* __restrict__ order, const int32_t* __restrict__ group_ids,
     int num_groups) {
-    const int idx = blockIdx.x * kBlock + threadIdx.x;
-    if (idx >= P) return;
-    depth_keys[idx] = preprocess_one<C>(idx, W, H, sh_degree, sh_coeffs, tanfovx, tanfovy, focal_x, focal_y, scale_modifier,
-                                        means3D, colors_precomp, shs, opacities, scales, rotations, cov3D_precomp, viewmatrix,
-                                        projmatrix, campos, rec, clamped_out, radii, tiles_touched, group_ids, num_groups);
-    order[idx] = (uint32_t)idx;
+    // The workgroup's records are staged in LDS and written as ONE contiguous range: a thread storing its own 48..80-byte
+    // record makes every store instruction touch 64 different cache lines.
+    constexpr int NV = rec_vec4(C);
+    __shared__ float4 s_rec[kBlock * NV];
+    const int tid = threadIdx.x;
+    const int idx = blockIdx.x * kBlock + tid;
+    if (idx < P) {
+        depth_keys[idx] = preprocess_one<C>(idx, W, H, sh_degree, sh_coeffs, tanfovx, tanfovy, focal_x, focal_y, scale_modifier,
+                                            means3D, colors_precomp, shs, opacities, scales, rotations, cov3D_precomp, viewmatrix,
+                                            projmatrix, campos, s_rec + tid * NV, clamped_out, radii, tiles_touched, group_ids,
+                                            num_groups);
+        order[idx] = (uint32_t)idx;
+    }
+    __syncthreads();
+    const size_t row0 = (size_t)blockIdx.x * kBlock;
+    const int n4 = min(kBlock, P - (int)row0) * NV;
+    float4* __restrict__ out = rec + row0 * NV;
+    for (int e = tid; e < n4; e += kBlock) out[e] = s_rec[e];
 }
 
 // Tiny pass (P <= kTinyMaxP; the SAM refiner's single-Gaussian footprint queries, utils/sam_refinement_utils.py:330-403,
@@ -273,7 +286,7 @@ __global__ __launch_bounds__(kTinyMaxP) void tiny_geometry_kernel(
     if (idx < P)
         key = preprocess_one<C>(idx, W, H, sh_degree, sh_coeffs, tanfovx, tanfovy, focal_x, focal_y, scale_modifier, means3D,
                                 colors_precomp, shs, opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
-                                campos, rec, clamped_out, radii, nullptr, nullptr, 0);
+                                campos, rec + (size_t)idx * rec_vec4(C), clamped_out, radii, nullptr, nullptr, 0);
     s_key[idx] = key;
     __syncthreads();
     if (idx < P) {
