@@ -69,6 +69,7 @@ __global__ __launch_bounds__(kBlock) void pack_sorted_kernel(const uint2* __rest
     constexpr int NV = rec_vec4(C);
     constexpr int SV = stream_vec4(C);
     __shared__ uint64_t wave_tot[kBlock / kWave];
+    __shared__ float4 s_rec[kBlock * SV];
     const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;   // virtual tile: image (group) * tiles + tile in the image
     const int timg = tile % tiles;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -122,9 +123,12 @@ __global__ __launch_bounds__(kBlock) void pack_sorted_kernel(const uint2* __rest
         const uint64_t pos = before + inc - mine;          // exclusive position inside this chunk, per quadrant
         if (mask) {
             // ONE copy of the record, COMPACTED: kept entry number c of the tile goes to record range.x + c (depth
-            // order preserved; consecutive kept threads -> consecutive 16*SV-byte records) ...
-            const uint32_t c_idx = running[4] + ((uint32_t)(pos >> 48) & 0xFFFu);
-            float4* dst = stream + ((size_t)range.x + (size_t)c_idx) * SV;
+            // order preserved).  The chunk's kept records are staged in LDS and written below by the whole workgroup
+            // as one contiguous range (a thread storing its own 16*SV-byte record makes every store instruction touch
+            // 64 different cache lines) ...
+            const uint32_t c_loc = (uint32_t)(pos >> 48) & 0xFFFu;
+            const uint32_t c_idx = running[4] + c_loc;
+            float4* dst = s_rec + c_loc * SV;
             dst[0] = make_float4(a.x, a.y, -0.5f * b.x, -b.y);
             dst[1] = make_float4(-0.5f * b.z, h, b.w, __uint_as_float(gid_of_thread));
             // features (gathered only now: 52 % of the bench scene's entries reach no quadrant), then the view
@@ -151,6 +155,12 @@ __global__ __launch_bounds__(kBlock) void pack_sorted_kernel(const uint2* __rest
                 }
             }
             quad_list[(size_t)range.x * 5 + (size_t)4 * n + c_idx] = (uint32_t)i;
+        }
+        __syncthreads();
+        {
+            const int kept4 = (int)((uint32_t)(total >> 48) & 0xFFFu) * SV;
+            float4* __restrict__ out = stream + ((size_t)range.x + (size_t)running[4]) * SV;
+            for (int e = tid; e < kept4; e += kBlock) out[e] = s_rec[e];
         }
 #pragma unroll
         for (int q = 0; q < 5; ++q) running[q] += (uint32_t)(total >> (12 * q)) & 0xFFFu;
