@@ -383,20 +383,51 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
             fold.push(w, q, __float_as_uint(cur[7]), cur[0], cur[1], grad_rec, lane);
         }
     };
-    // back-to-front over the quadrant's index stream (see blend_fwd.hip): two records in flight, their indices
-    // fetched one iteration ahead; reads below index 0 land in the previous region / the front pad and are clamped
-    StreamRec<C> recA, recB;
+    // back-to-front over the quadrant's index stream (see blend_fwd.hip); reads below index 0 land in the previous
+    // region / the front pad and are clamped
     const uint32_t* __restrict__ q = qi + (hi - 1);
-    uint32_t i1 = q[-1], i2 = q[-2];
-    recA.load(rec_at(q[0]));
-    for (int idx = hi - 1; idx >= 0; idx -= 2) {
-        recB.load(rec_at(i1));
-        const uint32_t n3 = q[-3], n4 = q[-4];
-        consume(recA, idx);
-        recA.load(rec_at(i2));
-        if (idx > 0) consume(recB, idx - 1);
-        i1 = n3; i2 = n4;
-        q -= 2;
+    // the loop only touches the geometry and the first GC features of a record: 12 dwords for GC <= 3 without depth
+    constexpr bool kBatched = GC <= 3 && !DEPTH;
+    if constexpr (kBatched) {
+        // batches of two records with pinned scalar waits, as the forward walks (blend_fwd.hip): SMEM returns out of
+        // order, so the only wait there is is lgkmcnt(0) = "everything in flight" -- placed BEFORE the next batch is
+        // issued, every record load gets two entries' worth of work to arrive.  (The one-ahead ping-pong below waits
+        // right after issuing its next load, i.e. for that load too: SQ counters showed 36 % of this kernel's
+        // wave-cycles parked on s_waitcnt.)  Four record register sets = 48 SGPRs here.
+        StreamRec<C> a0, a1, b0, b1;
+        uint32_t i2 = q[-2], i3 = q[-3], i4 = q[-4], i5 = q[-5];
+        a0.load(rec_at(q[0]));
+        a1.load(rec_at(q[-1]));
+        for (int idx = hi - 1; idx >= 0; idx -= 4) {
+            wait_scalar_loads();
+            b0.load(rec_at(i2));
+            b1.load(rec_at(i3));
+            const uint32_t n6 = q[-6], n7 = q[-7], n8 = q[-8], n9 = q[-9];
+            consume(a0, idx);
+            if (idx >= 1) consume(a1, idx - 1);
+            wait_scalar_loads();
+            a0.load(rec_at(i4));
+            a1.load(rec_at(i5));
+            if (idx >= 2) consume(b0, idx - 2);
+            if (idx >= 3) consume(b1, idx - 3);
+            i2 = n6; i3 = n7; i4 = n8; i5 = n9;
+            q -= 4;
+        }
+    } else {
+        // two ping-pong records, their indices fetched one iteration ahead (wider records: four sets would not fit
+        // the scalar register file)
+        StreamRec<C> recA, recB;
+        uint32_t i1 = q[-1], i2 = q[-2];
+        recA.load(rec_at(q[0]));
+        for (int idx = hi - 1; idx >= 0; idx -= 2) {
+            recB.load(rec_at(i1));
+            const uint32_t n3 = q[-3], n4 = q[-4];
+            consume(recA, idx);
+            recA.load(rec_at(i2));
+            if (idx > 0) consume(recB, idx - 1);
+            i1 = n3; i2 = n4;
+            q -= 2;
+        }
     }
     if (fold.cnt > 0) fold.flush(grad_rec, lane);
     pf.retire(reinterpret_cast<uint32_t*>(grad_rec), W);
