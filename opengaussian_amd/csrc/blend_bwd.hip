@@ -123,7 +123,16 @@ struct RankOneFold {
     // one accepted entry: this lane's weight, the entry's Gaussian (wave-uniform)
     __device__ __forceinline__ void push(float wl, uint32_t g, ACC* __restrict__ grad_rec, int lane) {
         w[cnt * kFoldStride + lane] = wl;
-        gidv = lane == cnt ? g : gidv;                 // a select, not a branch
+        // lane cnt of the id register <- the wave-uniform id: one v_writelane_b32 (lane select in M0, saved and restored;
+        // see PairFold::push) instead of a scalar-to-VGPR move plus a select
+        uint32_t m0_saved;
+        asm volatile(
+            "s_mov_b32 %1, m0\n\t"
+            "s_mov_b32 m0, %3\n\t"
+            "v_writelane_b32 %0, %2, m0\n\t"
+            "s_mov_b32 m0, %1"
+            : "+v"(gidv), "=&s"(m0_saved)
+            : "s"(g), "s"(cnt));
         ++cnt;
         if (cnt == kFoldRows) flush(grad_rec, lane);
     }
