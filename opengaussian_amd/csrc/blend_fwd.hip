@@ -198,7 +198,7 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
     // index -> record address; whatever the two-ahead prefetch reads past the end of the region is clamped
     auto rec_at = [&](uint32_t i) { return tb + (size_t)(min(i, lim) * (uint32_t)RS); };
     RecordPrefetch pf;
-    pf.issue(tb, n_tile, RS, tid, pf_lines);
+    pf.issue(tb, n_kept, RS, tid, pf_lines);
 
     // The loop is written to be SCALAR-ALU frugal (rocprof: the first version issued more SALU than VALU
     // instructions -- one scalar unit per CU -- because every nested divergent `if` costs exec-mask ops):
