@@ -233,11 +233,13 @@ int ogs_raster_export_binning(const OgsRasterFwdArgs* args, int64_t num_rendered
 int ogs_prof_enable(int on);
 int ogs_prof_collect(char* buf, size_t n);
 
-/* Test hook, not part of the reference boundary: runs the wave64 16-slot transposed reduction of the
- * backward blend on in[64][16]; out[lane] = sum over lanes of slot (lane >> 2). */
+/* Test hook, not part of the reference boundary: runs the wave64 16-slot transposed reduction (mask reductions,
+ * include/ogs_mask.h) on in[64][16]; out[lane] = sum over lanes of slot (lane >> 2). */
 int ogs_selftest_wave_fold16(const float* in, float* out, void* stream);
-/* Same for the 8-slot fold of the features-only backward: in[64][8]; out[lane] = sum over lanes of slot (lane >> 3). */
-int ogs_selftest_wave_fold8(const float* in, float* out, void* stream);
+/* Test hook: the heaviest-first workgroup order of the pack / blend kernels for tile ranges[vtiles][2] (start, end):
+ * order[vtiles] = a permutation of the tiles, non-increasing in the length class of their lists -- or the identity
+ * when the longest list is at most twice the mean (and for more than 65536 tiles). */
+int ogs_selftest_tile_order(const uint32_t* ranges, int64_t vtiles, uint32_t* order, void* stream);
 
 #ifdef __cplusplus
 }

@@ -532,20 +532,13 @@ __global__ __launch_bounds__(kBlock) void blend_backward_feat_kernel(
     pf.retire(reinterpret_cast<uint32_t*>(grad_rec), W);
 }
 
-// self-test hook for the fold: in [64 lanes][16 slots] -> out[lane] = value left in each lane
+// self-test hook for the 16-slot fold (wave_fold.h; used by mask_ops.hip): in [64 lanes][16 slots] -> out[lane] = value left in each lane
 __global__ void wave_fold16_test_kernel(const float* __restrict__ in, float* __restrict__ out) {
     float v[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = in[threadIdx.x * 16 + k];
     out[threadIdx.x] = wave_fold16(v);
 }
-__global__ void wave_fold8_test_kernel(const float* __restrict__ in, float* __restrict__ out) {
-    float v[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = in[threadIdx.x * 8 + k];
-    out[threadIdx.x] = wave_fold8(v);
-}
-
 template <int C, typename ACC>
 int launch_c(const OgsRasterBwdArgs& a, const ImageState& is, void* grad_rec_, hipStream_t s) {
     ACC* grad_rec = static_cast<ACC*>(grad_rec_);
@@ -607,12 +600,6 @@ int launch_acc(const OgsRasterBwdArgs& a, const ImageState& is, void* grad_rec, 
 int launch_blend_backward(const OgsRasterBwdArgs& a, const ImageState& is, void* grad_rec, bool f64, hipStream_t s) {
     if (a.num_rendered <= 0) return OGS_OK;
     return f64 ? launch_acc<double>(a, is, grad_rec, s) : launch_acc<float>(a, is, grad_rec, s);
-}
-
-int launch_wave_fold8_test(const float* in, float* out, hipStream_t s) {
-    OGS_LAUNCH(wave_fold8_test_kernel, dim3(1), dim3(kWave), 0, s, in, out);
-    OGS_LAUNCH_CHECK(1, s);
-    return OGS_OK;
 }
 
 int launch_wave_fold16_test(const float* in, float* out, hipStream_t s) {

@@ -567,6 +567,13 @@ const uint32_t* launch_tile_order(const ImageState& is, int64_t vtiles, hipStrea
     return order;
 }
 
+int launch_tile_order_test(const uint32_t* ranges, int64_t vtiles, uint32_t* order, hipStream_t s) {
+    if (vtiles > kOrderMaxTiles) { set_error("selftest: more than %lld tiles", (long long)kOrderMaxTiles); return OGS_ERR_UNSUPPORTED; }
+    OGS_LAUNCH(tile_order_kernel, dim3(1), dim3(kOrderThreads), 0, s, (const uint2*)ranges, (uint32_t)vtiles, order);
+    OGS_LAUNCH_CHECK(1, s);
+    return OGS_OK;
+}
+
 int launch_blend_forward(const OgsRasterFwdArgs& a, const GeomState& gs, const ImageState& is, int64_t D,
                          hipStream_t s) {
     switch (a.C) {

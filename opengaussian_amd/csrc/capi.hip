@@ -327,9 +327,9 @@ int ogs_selftest_wave_fold16(const float* in, float* out, void* stream_) {
     return launch_wave_fold16_test(in, out, static_cast<hipStream_t>(stream_));
 }
 
-int ogs_selftest_wave_fold8(const float* in, float* out, void* stream_) {
-    if (!in || !out) { set_error("selftest: NULL pointer"); return OGS_ERR_INVALID_ARG; }
-    return launch_wave_fold8_test(in, out, static_cast<hipStream_t>(stream_));
+int ogs_selftest_tile_order(const uint32_t* ranges, int64_t vtiles, uint32_t* order, void* stream_) {
+    if (!ranges || !order || vtiles <= 0) { set_error("selftest: NULL pointer / no tiles"); return OGS_ERR_INVALID_ARG; }
+    return launch_tile_order_test(ranges, vtiles, order, static_cast<hipStream_t>(stream_));
 }
 
 int ogs_raster_export_binning(const OgsRasterFwdArgs* a, int64_t D, uint64_t* keys_out, uint32_t* ranges_out,

@@ -292,7 +292,7 @@ inline bool backward_is_features_only(const OgsRasterBwdArgs& a) {
 int launch_sh_grad_from_views(int P, int V, int sh_degree, int sh_coeffs, const float* means3D, const float* campos,
                               const float* dL_drgb, float* dL_dsh, hipStream_t s);
 int launch_wave_fold16_test(const float* in, float* out, hipStream_t s);
-int launch_wave_fold8_test(const float* in, float* out, hipStream_t s);
+int launch_tile_order_test(const uint32_t* ranges, int64_t vtiles, uint32_t* order, hipStream_t s);
 int launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
 int launch_export_keys(const uint2* ranges, int tiles, const uint32_t* point_list, const float4* rec, int recv4,
                        uint64_t* keys_out, hipStream_t s);

@@ -52,38 +52,4 @@ __device__ __forceinline__ float wave_fold16(float v[16]) {
     return y;
 }
 
-// Same for 8 per-lane slots (the features-only backward: <= 8 channels and nothing else): on return lane L holds
-// the sum over all 64 lanes of slot (L>>3).  ~17 VALU instead of ~35.
-__device__ __forceinline__ float wave_fold8(float v[8]) {
-    const int lane = lane_id();
-    float u[4];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {                      // lane bit 5 selects slot + 4
-        auto ra = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2 * j]), __float_as_uint(v[2 * j + 4]), false, false);
-        auto rb = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[2 * j + 1]), __float_as_uint(v[2 * j + 5]), false, false);
-        const v2f lo = {__uint_as_float(ra[0]), __uint_as_float(rb[0])};
-        const v2f hi = {__uint_as_float(ra[1]), __uint_as_float(rb[1])};
-        const v2f t = lo + hi;
-        u[2 * j] = t.x; u[2 * j + 1] = t.y;
-    }
-    float w[2];
-    {                                                  // lane bit 4 selects slot + 2
-        auto ra = __builtin_amdgcn_permlane16_swap(__float_as_uint(u[0]), __float_as_uint(u[2]), false, false);
-        auto rb = __builtin_amdgcn_permlane16_swap(__float_as_uint(u[1]), __float_as_uint(u[3]), false, false);
-        const v2f lo = {__uint_as_float(ra[0]), __uint_as_float(rb[0])};
-        const v2f hi = {__uint_as_float(ra[1]), __uint_as_float(rb[1])};
-        const v2f t = lo + hi;
-        w[0] = t.x; w[1] = t.y;
-    }
-    const bool b3 = (lane & 8) != 0;                   // lane bit 3 selects slot + 1
-    const float keep = b3 ? w[1] : w[0];
-    const float send = b3 ? w[0] : w[1];
-    float y = keep + dpp_mov<0x128>(send);             // row_ror:8
-    y += dpp_mov<0xB1>(y);                             // quad_perm [1,0,3,2]
-    y += dpp_mov<0x4E>(y);                             // quad_perm [2,3,0,1]
-    y += dpp_mov<0x141>(y);                            // row_half_mirror: lane ^ 4 up to the (now equal) low bits
-    return y;
-}
-
-
 }  // namespace ogs

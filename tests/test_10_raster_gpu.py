@@ -68,18 +68,36 @@ def test_wave_fold16(gpu_device):
         torch.testing.assert_close(out.cpu(), expect, rtol=1e-5, atol=1e-4)
 
 
-def test_wave_fold8(gpu_device):
+def test_tile_order_is_a_heaviest_first_permutation(gpu_device):
+    """blend_fwd.hip::tile_order_kernel: any permutation is a valid schedule; the point is that long lists start first
+    (non-increasing pseudo-log length class) and that balanced lists keep the raster order."""
     from opengaussian_amd import _lib
-    g = torch.Generator().manual_seed(1)
-    x = torch.randn(64, 8, generator=g)
-    xi = (torch.arange(64)[:, None] * 13 + torch.arange(8)[None, :] * 5 + 1).float()
-    for inp in (x, xi):
-        d = inp.to(gpu_device).contiguous()
-        out = torch.zeros(64, device=gpu_device)
-        _lib.check(_lib.lib().ogs_selftest_wave_fold8(d.data_ptr(), out.data_ptr(), 0), "selftest")
+
+    def run(lengths):
+        n = len(lengths)
+        start = torch.cumsum(torch.cat([torch.zeros(1, dtype=torch.int64), lengths[:-1]]), 0)
+        ranges = torch.stack([start, start + lengths], 1).to(torch.int32).to(gpu_device).contiguous()
+        order = torch.full((n,), -1, dtype=torch.int32, device=gpu_device)
+        _lib.check(_lib.lib().ogs_selftest_tile_order(ranges.data_ptr(), n, order.data_ptr(), 0), "selftest")
         torch.cuda.synchronize()
-        expect = inp.double().sum(0)[torch.arange(64) // 8].float()
-        torch.testing.assert_close(out.cpu(), expect, rtol=1e-5, atol=1e-4)
+        return order.cpu().long()
+
+    def work_class(n):                       # the kernel's scale: exact below 8, then exponent * 8 + 3 mantissa bits
+        n = int(n)
+        if n < 8:
+            return n
+        e = n.bit_length() - 1
+        return min(e * 8 + ((n >> (e - 3)) & 7), 255)
+
+    g = torch.Generator().manual_seed(3)
+    skewed = (torch.rand(8160, generator=g) ** 6 * 20000).long()            # two orders of magnitude, many empty tiles
+    o = run(skewed)
+    assert torch.equal(torch.sort(o).values, torch.arange(8160))            # a permutation
+    cls = torch.tensor([work_class(skewed[t]) for t in o.tolist()])
+    assert (cls[1:] <= cls[:-1]).all()                                       # heaviest class first
+    balanced = 900 + (torch.rand(8160, generator=g) * 200).long()          # longest <= 2 x mean: raster order
+    assert torch.equal(run(balanced), torch.arange(8160))
+    assert torch.equal(torch.sort(run(torch.tensor([5, 0, 700, 3]))).values, torch.arange(4))
 
 
 @pytest.mark.parametrize("mode", ["feat3", "feat6", "fused9", "grouped6"])
