@@ -126,6 +126,22 @@ def _tiny_scratch(dev, stream: int, lib):
     return sc
 
 
+_BG_TILED: dict = {}
+
+
+def _tiled_bg(bg: torch.Tensor, Cn: int) -> torch.Tensor:
+    """the 3-wide background tiled over a fused pass's channels; cached per (storage, version): training passes the same
+    background tensor every iteration and a `repeat` is a launch plus an allocation on a path that is all host time"""
+    key = (bg.data_ptr(), bg._version, Cn, bg.device)
+    hit = _BG_TILED.get(key)
+    if hit is None:
+        if len(_BG_TILED) > 16:
+            _BG_TILED.clear()
+        hit = (bg, bg.repeat(Cn // 3))        # the source is held too: its address cannot be recycled while cached
+        _BG_TILED[key] = hit
+    return hit[1]
+
+
 def _require_gpu(t: torch.Tensor, name: str):
     if not t.is_cuda:
         raise RuntimeError(f"{name} must live on the GPU (got {t.device}); the MI355X rasterizer has no CPU path")
@@ -248,7 +264,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             if bg is not None and bg.numel() == 3 and Cn > 3:
                 # the facade's bg is 3-wide and the reference applies it to EVERY 3-channel pass (RGB, feat[:, :3],
                 # feat[:, 3:6], gaussian_renderer/__init__.py:55-70,129-151): tile it over the fused channels
-                bg = bg.repeat(Cn // 3)
+                bg = _tiled_bg(bg, Cn)
             else:
                 raise RuntimeError(f"bg must have {Cn} entries")
         view = _f32c(rs.viewmatrix.to(dev))
