@@ -129,6 +129,7 @@ struct RankOneFold {
         asm volatile(
             "s_mov_b32 %1, m0\n\t"
             "s_mov_b32 m0, %3\n\t"
+            "s_nop 0\n\t"
             "v_writelane_b32 %0, %2, m0\n\t"
             "s_mov_b32 m0, %1"
             : "+v"(gidv), "=&s"(m0_saved)
@@ -253,6 +254,7 @@ struct PairFold {
         asm volatile(
             "s_mov_b32 %3, m0\n\t"
             "s_mov_b32 m0, %7\n\t"
+            "s_nop 0\n\t"                       // inline asm is opaque to the hazard recognizer: one wait state after the M0 write
             "v_writelane_b32 %0, %4, m0\n\t"
             "v_writelane_b32 %1, %5, m0\n\t"
             "v_writelane_b32 %2, %6, m0\n\t"
