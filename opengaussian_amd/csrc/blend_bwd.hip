@@ -552,7 +552,7 @@ int launch_c(const OgsRasterBwdArgs& a, const ImageState& is, void* grad_rec_, h
     const float* stream = (const float*)stream_base<C>(const_cast<void*>(a.sorted_rec));
     const uint32_t* quads = quad_base(const_cast<void*>(a.quad_list));
     const unsigned vtiles = (unsigned)(gx * gy) * (unsigned)num_groups_of(a.num_groups);
-    const uint32_t* order = tile_order_of(is, vtiles);          // the forward's heaviest-first order (blend_fwd.hip)
+    const uint32_t* order = tile_order_of(is, vtiles, a.P);     // the forward's heaviest-first order (blend_fwd.hip)
     if (backward_is_features_only(a)) {
         // only dL/dcolors_precomp is owed (stages >= 1, train.py:431-436): no alpha recursion, no geometry partials
 #define OGS_BWD_FEAT(F0V)                                                                                             \

@@ -190,8 +190,9 @@ struct ImageState {     // kept until backward
 };
 // heaviest-first workgroup order of the per-tile kernels; returns the array the kernels index with blockIdx.x, or
 // nullptr (identity) when the ordering is off (OGS_TILE_ORDER=0) or not worth a launch
-const uint32_t* launch_tile_order(const ImageState& is, int64_t vtiles, hipStream_t s, int debug);
-const uint32_t* tile_order_of(const ImageState& is, int64_t vtiles);      // what the forward of this pass used
+// (P: a pass with fewer than four Gaussians per tile is all launch latency -- no ordering, one launch less)
+const uint32_t* launch_tile_order(const ImageState& is, int64_t vtiles, int P, hipStream_t s, int debug);
+const uint32_t* tile_order_of(const ImageState& is, int64_t vtiles, int P);      // what the forward of this pass used
 int launch_export_n_contrib(const OgsRasterFwdArgs& a, const ImageState& is, uint32_t* out, hipStream_t s);
 
 // radix sort / scan (binning.hip) ---------------------------------------------------------------
