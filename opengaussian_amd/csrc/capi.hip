@@ -183,17 +183,23 @@ int ogs_raster_forward_geometry(const OgsRasterFwdArgs* a, void* stream_, int64_
     if (a->P == 0) return OGS_OK;
     const GeomState gs = GeomState::carve(a->geom_buffer, a->P, a->C);
     const GeomTmp gt = GeomTmp::carve(a->geom_tmp, a->P);
-    rc = launch_preprocess(*a, gs, gt, s);
-    if (rc != OGS_OK) return rc;
-    // depth sort of the P Gaussians: 4 x 8-bit stable passes, ends in keys[0]/order[0]
-    for (int pass = 0; pass < 4; ++pass) {
-        const int in = pass & 1, out = in ^ 1;
-        rc = radix_pass(gt.keys[in], gt.order[in], gt.keys[out], gt.order[out], a->P, 8 * pass, 8, gt.sort_tmp, s, a->debug);
+    if (a->P <= kSmallMaxP) {
+        // small pass: preprocess + depth order + scan in ONE single-workgroup launch instead of 15 (preprocess_fwd.hip)
+        rc = launch_small_geometry(*a, gs, gt, s);
+        if (rc != OGS_OK) return rc;
+    } else {
+        rc = launch_preprocess(*a, gs, gt, s);
+        if (rc != OGS_OK) return rc;
+        // depth sort of the P Gaussians: 4 x 8-bit stable passes, ends in keys[0]/order[0]
+        for (int pass = 0; pass < 4; ++pass) {
+            const int in = pass & 1, out = in ^ 1;
+            rc = radix_pass(gt.keys[in], gt.order[in], gt.keys[out], gt.order[out], a->P, 8 * pass, 8, gt.sort_tmp, s, a->debug);
+            if (rc != OGS_OK) return rc;
+        }
+        // offsets[r] = exclusive scan of tiles_touched in depth order; total = num_rendered
+        rc = exclusive_scan_u32(gt.tiles_touched, gt.order[0], gt.offsets, a->P, gt.num_rendered, gt.sort_tmp, s, a->debug);
         if (rc != OGS_OK) return rc;
     }
-    // offsets[r] = exclusive scan of tiles_touched in depth order; total = num_rendered
-    rc = exclusive_scan_u32(gt.tiles_touched, gt.order[0], gt.offsets, a->P, gt.num_rendered, gt.sort_tmp, s, a->debug);
-    if (rc != OGS_OK) return rc;
     if (num_rendered_host) {       // blocking read-back (what the reference does once per forward)
         uint32_t d = 0;
         OGS_HIP_CHECK(hipMemcpyAsync(&d, gt.num_rendered, sizeof(uint32_t), hipMemcpyDeviceToHost, s));

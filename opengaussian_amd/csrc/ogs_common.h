@@ -15,6 +15,7 @@ constexpr int kTile = OGS_TILE;      // 16x16 pixel tiles
 constexpr int kBlock = 256;          // 4 wave64 per workgroup everywhere
 constexpr int kWave = 64;
 constexpr int kTinyMaxP = 256;       // largest P of the tiny pass (one workgroup does the whole geometry phase)
+constexpr int kSmallMaxP = 1024;     // largest P whose geometry phase (preprocess + depth sort + scan) is ONE workgroup
 
 // ---- error plumbing -------------------------------------------------------------------------
 void set_error(const char* fmt, ...);
@@ -268,6 +269,7 @@ struct BinTmp {         // transient, render phase
 // kernels launched by capi.hip ------------------------------------------------------------------
 int launch_preprocess(const OgsRasterFwdArgs& a, const GeomState& gs, const GeomTmp& gt, hipStream_t s);
 int launch_tiny_geometry(const OgsRasterFwdArgs& a, const GeomState& gs, uint32_t* order, hipStream_t s);
+int launch_small_geometry(const OgsRasterFwdArgs& a, const GeomState& gs, const GeomTmp& gt, hipStream_t s);
 int launch_tiny_blend(const OgsRasterFwdArgs& a, const GeomState& gs, const uint32_t* order, hipStream_t s);
 int launch_duplicate(const OgsRasterFwdArgs& a, const GeomState& gs, const GeomTmp& gt, uint32_t* tile_keys,
                      uint32_t* vals, uint32_t capacity, hipStream_t s);

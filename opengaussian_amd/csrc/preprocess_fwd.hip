@@ -299,6 +299,67 @@ __global__ __launch_bounds__(kTinyMaxP) void tiny_geometry_kernel(
     }
 }
 
+// Small pass (kTinyMaxP < P <= kSmallMaxP: the subset renders of stages 2.2 / 3, un-batched leaf loops): the geometry
+// phase of the streaming path -- preprocess, four radix passes of three launches each, a two-launch scan: 15 launches of
+// pure latency at this size -- as ONE workgroup: every thread preprocesses one Gaussian (same code as the streaming
+// kernel), the depth order comes from a rank sort on (depth bits, index) in LDS (= what the stable radix passes
+// produce) and the exclusive scan of tiles_touched in that order from a block scan.  Leaves order[0], offsets and
+// num_rendered exactly as the streaming kernels do; the render phase follows unchanged.
+template <int C>
+__global__ __launch_bounds__(kSmallMaxP) void small_geometry_kernel(
+    int P, int W, int H, int sh_degree, int sh_coeffs, float tanfovx, float tanfovy, float focal_x, float focal_y,
+    float scale_modifier, const float* __restrict__ means3D, const float* __restrict__ colors_precomp,
+    const float* __restrict__ shs, const float* __restrict__ opacities, const float* __restrict__ scales,
+    const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp, const float* __restrict__ viewmatrix,
+    const float* __restrict__ projmatrix, const float* __restrict__ campos, float4* __restrict__ rec,
+    uint32_t* __restrict__ clamped_out, int32_t* __restrict__ radii, uint32_t* __restrict__ order,
+    uint32_t* __restrict__ offsets, uint32_t* __restrict__ num_rendered, const int32_t* __restrict__ group_ids,
+    int num_groups) {
+    __shared__ uint32_t s_key[kSmallMaxP];
+    __shared__ uint32_t s_touched[kSmallMaxP];      // by Gaussian index, then by depth rank
+    __shared__ uint32_t s_sorted[kSmallMaxP];
+    __shared__ uint32_t s_wave[kSmallMaxP / kWave];
+    const int idx = threadIdx.x, lane = idx & 63, wave = idx >> 6;
+    uint32_t key = 0xFFFFFFFFu;
+    s_touched[idx] = 0u;
+    if (idx < P)
+        key = preprocess_one<C>(idx, W, H, sh_degree, sh_coeffs, tanfovx, tanfovy, focal_x, focal_y, scale_modifier, means3D,
+                                colors_precomp, shs, opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
+                                campos, rec + (size_t)idx * rec_vec4(C), clamped_out, radii, s_touched, group_ids, num_groups);
+    s_key[idx] = key;
+    __syncthreads();
+    int rank = idx;                                  // threads past P keep their own slot (touched = 0)
+    if (idx < P) {
+        rank = 0;
+        for (int j = 0; j < P; ++j) {
+            const uint32_t kj = s_key[j];            // wave-uniform address: broadcast read
+            rank += (kj < key || (kj == key && j < idx)) ? 1 : 0;
+        }
+        order[rank] = (uint32_t)idx;
+    }
+    s_sorted[rank] = s_touched[idx];
+    __syncthreads();
+    // exclusive scan over the depth order: wave scan, then the sixteen wave totals
+    const uint32_t v = s_sorted[idx];
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, kWave);
+        if (lane >= d) incl += o;
+    }
+    if (lane == kWave - 1) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0u, total = 0u;
+#pragma unroll
+    for (int w = 0; w < kSmallMaxP / kWave; ++w) {
+        const uint32_t t = s_wave[w];
+        if (w < wave) before += t;
+        total += t;
+    }
+    if (idx < P) offsets[idx] = before + incl - v;
+    if (idx == 0) *num_rendered = total;
+}
+
 // Emit one (tile id, Gaussian id) pair per touched tile, Gaussians visited in DEPTH order so that a
 // stable sort by tile id alone reproduces the reference's (tile<<32 | depth_bits) order with ties
 // broken by Gaussian index (DESIGN.md "binning").
@@ -433,7 +494,29 @@ int launch_tiny_geometry_c(const OgsRasterFwdArgs& a, const GeomState& gs, uint3
     return OGS_OK;
 }
 
+template <int C>
+int launch_small_geometry_c(const OgsRasterFwdArgs& a, const GeomState& gs, const GeomTmp& gt, hipStream_t s) {
+    const float focal_x = (float)a.W / (2.0f * a.tanfovx);
+    const float focal_y = (float)a.H / (2.0f * a.tanfovy);
+    OGS_LAUNCH(small_geometry_kernel<C>, dim3(1), dim3(kSmallMaxP), 0, s, a.P, a.W, a.H, a.sh_degree, a.sh_coeffs, a.tanfovx,
+               a.tanfovy, focal_x, focal_y, a.scale_modifier, a.means3D, a.colors_precomp, a.shs, a.opacities, a.scales,
+               a.rotations, a.cov3D_precomp, a.viewmatrix, a.projmatrix, a.campos, gs.rec, gs.clamped, a.radii, gt.order[0],
+               gt.offsets, gt.num_rendered, a.num_groups > 1 ? a.group_ids : (const int32_t*)nullptr, a.num_groups);
+    OGS_LAUNCH_CHECK(a.debug, s);
+    return OGS_OK;
+}
+
 }  // namespace
+
+int launch_small_geometry(const OgsRasterFwdArgs& a, const GeomState& gs, const GeomTmp& gt, hipStream_t s) {
+    switch (a.C) {
+        case 3: return launch_small_geometry_c<3>(a, gs, gt, s);
+        case 6: return launch_small_geometry_c<6>(a, gs, gt, s);
+        case 9: return launch_small_geometry_c<9>(a, gs, gt, s);
+        case 12: return launch_small_geometry_c<12>(a, gs, gt, s);
+        default: set_error("unsupported channel count C=%d (3, 6, 9 or 12)", a.C); return OGS_ERR_UNSUPPORTED;
+    }
+}
 
 int launch_tiny_geometry(const OgsRasterFwdArgs& a, const GeomState& gs, uint32_t* order, hipStream_t s) {
     switch (a.C) {

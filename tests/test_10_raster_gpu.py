@@ -30,6 +30,11 @@ CASES = [
     (1500, 100, 77, 90.0, 1, False, False),      # sizes not multiples of 16, colours precomputed
     (1200, 64, 48, 60.0, 2, True, True),         # cov3D_precomp path
     (5000, 320, 200, 250.0, 3, True, False),
+    # P <= 1024: the geometry phase is ONE workgroup (small_geometry_kernel: rank sort + block scan in LDS); depth ties
+    (700, 200, 120, 150.0, 3, True, False),
+    (1024, 96, 64, 80.0, 4, False, False),
+    (1025, 96, 64, 80.0, 4, False, False),       # first size on the radix path again
+    (257, 130, 70, 100.0, 6, True, True),
 ]
 
 
