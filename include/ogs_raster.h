@@ -77,7 +77,8 @@ typedef struct OgsRasterFwdArgs {
     void* geom_buffer;           /* ogs_raster_geom_bytes(P, C): kept until backward */
     void* geom_tmp;              /* ogs_raster_geom_tmp_bytes(P): must live across both forward calls */
     void* image_buffer;          /* ogs_raster_image_bytes(W, H): kept until backward */
-    uint32_t* point_list;        /* [num_rendered] sorted Gaussian ids: kept until backward (render phase) */
+    uint32_t* point_list;        /* [num_rendered] sorted Gaussian ids in bits 0..30; bit 31: the (Gaussian, tile) pair can
+                                  * reach a pixel of its tile (P < 2^31).  Kept until backward (render phase) */
     void* binning_tmp;           /* ogs_raster_binning_tmp_bytes(num_rendered, W, H) (render phase) */
     void* sorted_rec;            /* ogs_raster_sorted_bytes(num_rendered, C): one packed record per sorted-list entry,
                                     read by the blend kernels through the scalar path; kept until backward */

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(kBlock) void export_keys_kernel(const uint2* __rest
     const uint32_t tile = blockIdx.x;
     const uint2 r = ranges[tile];
     for (uint32_t i = r.x + threadIdx.x; i < r.y; i += kBlock) {
-        const uint32_t gid = point_list[i];
+        const uint32_t gid = point_list[i] & kGidMask;          // top bit: "reaches the tile" flag (ogs_common.h)
         const uint32_t bits = __float_as_uint(rec[(size_t)gid * recv4].z);
         keys_out[i] = ((uint64_t)tile << 32) | bits;
     }

@@ -31,22 +31,7 @@ namespace ogs {
 namespace {
 
 constexpr float kAlphaMin = 1.0f / 255.0f;
-constexpr float kThrMargin = 0.01f;
 typedef float v2f __attribute__((ext_vector_type(2)));   // register pair -> v_pk_fma_f32
-
-// max over the box d in [xlo,xhi] x [ylo,yhi] of  -0.5*(A dx^2 + C dy^2) - B dx dy   (A, C > 0, AC - B^2 > 0)
-__device__ __forceinline__ float max_power_in_box(float A, float B, float Cc, float xlo, float xhi, float ylo,
-                                                  float yhi) {
-    if (xlo <= 0.f && xhi >= 0.f && ylo <= 0.f && yhi >= 0.f) return 0.f;
-    auto q = [&](float dx, float dy) { return -0.5f * (A * dx * dx + Cc * dy * dy) - B * dx * dy; };
-    const float nbA = -B / A, nbC = -B / Cc;
-    // concave form, origin outside the box: the maximum sits on an edge, at the clamped 1-D maximiser
-    float m = q(xlo, fminf(fmaxf(nbC * xlo, ylo), yhi));
-    m = fmaxf(m, q(xhi, fminf(fmaxf(nbC * xhi, ylo), yhi)));
-    m = fmaxf(m, q(fminf(fmaxf(nbA * ylo, xlo), xhi), ylo));
-    m = fmaxf(m, q(fminf(fmaxf(nbA * yhi, xlo), xhi), yhi));
-    return m;
-}
 
 __device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d) {
     const uint32_t lo = __shfl_up((uint32_t)v, d, kWave), hi = __shfl_up((uint32_t)(v >> 32), d, kWave);
@@ -84,8 +69,12 @@ __global__ __launch_bounds__(kBlock) void pack_sorted_kernel(const uint2* __rest
         float4 a = make_float4(0, 0, 0, 0), b = a;
         float h = 0.f;
         uint32_t gid_of_thread = 0;
-        if (i < n) {
-            const uint32_t gid = point_list[range.x + i];
+        // sorted value = Gaussian id | "reaches this tile" << 31: duplicate_kernel ran ONE box test per (Gaussian, tile)
+        // pair while the Gaussian's geometry sat in LDS; nothing is gathered here for the 52 % of the pairs that reach
+        // no pixel of the tile
+        const uint32_t sv = i < n ? point_list[range.x + i] : 0u;
+        if (sv >> kReachBit) {
+            const uint32_t gid = sv & kGidMask;
             gid_of_thread = gid;
             const float4* src = rec + (size_t)gid * NV;
             a = src[0]; b = src[1];              // geometry only: the features are fetched if the entry survives

@@ -338,6 +338,29 @@ struct RecordPrefetch {
 };
 int blend_prefetch_lines();     // capi.hip: OGS_BLEND_PREFETCH (default kPrefetchMax)
 
+// ---- can a Gaussian reach a pixel box? ------------------------------------------------------------------------------
+// Candidate window of the blend loops: thr <= power <= 0 with thr = ln(1 / (255 * opacity)) - kThrMargin, i.e. alpha can
+// reach 1/255 (the margin absorbs the rounding differences between this test and the blend kernels' own evaluation of
+// the power).  duplicate_kernel (preprocess_fwd.hip) tests the whole 16x16 tile once per (Gaussian, tile) pair and
+// flags the pair in the top bit of the sorted value; pack_sorted_kernel (blend_fwd.hip) tests the four 8x8 quadrants
+// of the flagged pairs.
+constexpr float kThrMargin = 0.01f;
+constexpr int kReachBit = 31;                           // Gaussian ids are < 2^31
+constexpr uint32_t kGidMask = (1u << kReachBit) - 1u;
+// max over the box d in [xlo,xhi] x [ylo,yhi] of  -0.5*(A dx^2 + C dy^2) - B dx dy   (A, C > 0, AC - B^2 > 0)
+__device__ __forceinline__ float max_power_in_box(float A, float B, float Cc, float xlo, float xhi, float ylo,
+                                                  float yhi) {
+    if (xlo <= 0.f && xhi >= 0.f && ylo <= 0.f && yhi >= 0.f) return 0.f;
+    auto q = [&](float dx, float dy) { return -0.5f * (A * dx * dx + Cc * dy * dy) - B * dx * dy; };
+    const float nbA = -B / A, nbC = -B / Cc;
+    // concave form, origin outside the box: the maximum sits on an edge, at the clamped 1-D maximiser
+    float m = q(xlo, fminf(fmaxf(nbC * xlo, ylo), yhi));
+    m = fmaxf(m, q(xhi, fminf(fmaxf(nbC * xhi, ylo), yhi)));
+    m = fmaxf(m, q(fminf(fmaxf(nbA * ylo, xlo), xhi), ylo));
+    m = fmaxf(m, q(fminf(fmaxf(nbA * yhi, xlo), xhi), yhi));
+    return m;
+}
+
 // ---- tiny device helpers ------------------------------------------------------------------------
 // s_waitcnt lgkmcnt(0) (vmcnt / expcnt untouched), pinned in place: nothing is scheduled across it
 __device__ __forceinline__ void wait_scalar_loads() {

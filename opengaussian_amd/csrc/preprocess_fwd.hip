@@ -384,10 +384,14 @@ __global__ __launch_bounds__(kBlock) void duplicate_kernel(int P, int W, int H, 
     __shared__ uint32_t s_rect[kBlock];     // rminx | rminy << 12 | width << 24   (grids up to 4095 tiles a side)
     __shared__ uint32_t s_first, s_total;
     __shared__ uint32_t s_key0[kBlock];     // group * tiles: first virtual tile of the Gaussian's image
+    __shared__ float4 s_ctr[kBlock];        // centre x, y, reach threshold (ogs_common.h), conic B
+    __shared__ float2 s_con[kBlock];        // conic A, C
     const int tid = threadIdx.x;
     const int r = blockIdx.x * kBlock + tid;
     const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
     uint32_t off = 0, cnt = 0, gid = 0, rect = 1u << 24, key0 = 0;
+    float4 ctr = make_float4(0.f, 0.f, 0.f, 0.f);
+    float2 con = make_float2(1.f, 1.f);
     if (r < P) {
         gid = order[r];
         off = offsets[r];
@@ -396,6 +400,9 @@ __global__ __launch_bounds__(kBlock) void duplicate_kernel(int P, int W, int H, 
         const float4 a = rec[(size_t)gid * NV];
         const int radius = __float_as_int(a.w);
         if (radius > 0) {
+            const float4 b = rec[(size_t)gid * NV + 1];
+            ctr = make_float4(a.x, a.y, -(__logf(255.0f * b.w) + kThrMargin), b.y);
+            con = make_float2(b.x, b.z);
             const float rf = (float)radius;
             auto tr = [](float v) -> int {
                 if (!(fabsf(v) < 3.0e38f)) v = 0.f;
@@ -415,7 +422,8 @@ __global__ __launch_bounds__(kBlock) void duplicate_kernel(int P, int W, int H, 
                     uint32_t o = off;
                     for (int ty = rminy; ty < rmaxy; ++ty)
                         for (int tx = rminx; tx < rmaxx; ++tx) {
-                            if (o < capacity) { tile_keys[o] = key0 + (uint32_t)(ty * gx + tx); vals[o] = gid; }
+                            // footprints wider than 4080 px: flagged without a test (pack tests the quadrants)
+                            if (o < capacity) { tile_keys[o] = key0 + (uint32_t)(ty * gx + tx); vals[o] = gid | (1u << kReachBit); }
                             ++o;
                         }
                     rect |= 0u;            // slots of this Gaussian are skipped in the cooperative walk (marked below)
@@ -432,6 +440,8 @@ __global__ __launch_bounds__(kBlock) void duplicate_kernel(int P, int W, int H, 
     s_gid[tid] = gid;
     s_rect[tid] = rect;
     s_key0[tid] = key0;
+    s_ctr[tid] = ctr;
+    s_con[tid] = con;
     const int last = min(P - 1 - blockIdx.x * kBlock, kBlock - 1);
     if (tid == last) s_total = off - first + cnt;
     __syncthreads();
@@ -452,8 +462,15 @@ __global__ __launch_bounds__(kBlock) void duplicate_kernel(int P, int W, int H, 
         const uint32_t row = local / w, col = local - row * w;
         const uint32_t o = first + j;
         if (o < capacity) {
-            tile_keys[o] = s_key0[lo] + ((rc >> 12 & 0xFFFu) + row) * (uint32_t)gx + (rc & 0xFFFu) + col;
-            vals[o] = g;
+            const uint32_t tx = (rc & 0xFFFu) + col, ty = (rc >> 12 & 0xFFFu) + row;
+            tile_keys[o] = s_key0[lo] + ty * (uint32_t)gx + tx;
+            // can the Gaussian reach ANY pixel of this tile?  One box test per pair, here, while its geometry sits in
+            // LDS: pack_sorted_kernel then gathers records (and tests the four quadrants) only for the pairs that can
+            const float4 c = s_ctr[lo];
+            const float2 k = s_con[lo];
+            const float X0 = (float)(tx * kTile), Y0 = (float)(ty * kTile);
+            const float m = max_power_in_box(k.x, c.w, k.y, c.x - X0 - 15.f, c.x - X0, c.y - Y0 - 15.f, c.y - Y0);
+            vals[o] = g | ((m >= c.z ? 1u : 0u) << kReachBit);
         }
     }
 }

@@ -100,8 +100,38 @@ def hip_export_binning(color_tensor):
     _lib.check(_lib.lib().ogs_raster_export_binning(C.byref(a), D, ptr(keys), ptr(ranges), ptr(ncontrib),
                                                     torch.cuda.current_stream().cuda_stream), "export_binning")
     torch.cuda.synchronize()
+    # sorted values: Gaussian id in bits 0..30, bit 31 = "the pair can reach a pixel of its tile" (csrc/ogs_common.h)
+    raw = point_list[:D].cpu().numpy().view(np.uint32)
+    LAST_REACH_FLAGS[:] = [(raw >> 31).astype(bool)]
     return (keys[:D].cpu().numpy().view(np.uint64), ranges.cpu().numpy().view(np.uint32),
-            ncontrib.cpu().numpy().view(np.uint32), point_list[:D].cpu().numpy().view(np.uint32))
+            ncontrib.cpu().numpy().view(np.uint32), raw & np.uint32(0x7FFFFFFF))
+
+
+LAST_REACH_FLAGS = [None]       # reach flags of the most recent hip_export_binning call, parallel to its point list
+
+
+def assert_reach_flags_keep_every_contributor(flags, keys, point_list, geom, W, H):
+    """A pair flagged "cannot reach its tile" is dropped by pack: it must not be able to contribute.  Float64 check of
+    every dropped (Gaussian, tile) pair: alpha = opacity * exp(power) stays below 1/255 on all 256 pixel centres."""
+    dropped = np.nonzero(~flags)[0]
+    if dropped.size == 0:
+        return 0
+    gx = (W + 15) // 16
+    tile = (keys[dropped] >> np.uint64(32)).astype(np.int64)
+    gid = point_list[dropped].astype(np.int64)
+    x0 = (tile % gx) * 16.0
+    y0 = (tile // gx) * 16.0
+    px = x0[:, None, None] + np.arange(16, dtype=np.float64)[None, None, :]
+    py = y0[:, None, None] + np.arange(16, dtype=np.float64)[None, :, None]
+    dx = geom.xy[gid, 0].astype(np.float64)[:, None, None] - px
+    dy = geom.xy[gid, 1].astype(np.float64)[:, None, None] - py
+    A, B, Cc = (geom.conic[gid, k].astype(np.float64)[:, None, None] for k in range(3))
+    power = -0.5 * (A * dx * dx + Cc * dy * dy) - B * dx * dy
+    alpha = geom.opacity[gid].astype(np.float64)[:, None, None] * np.exp(np.minimum(power, 0.0))
+    alpha = np.where(power > 0, 0.0, alpha)
+    worst = float(alpha.max())
+    assert worst < 1.0 / 255.0, f"a dropped pair reaches alpha {worst} >= 1/255"
+    return int(dropped.size)
 
 
 def assert_close_modulo_threshold_flips(got, want, tol=1e-4, flip_tol=4e-3, max_pixels=2):

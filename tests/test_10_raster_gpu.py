@@ -48,6 +48,11 @@ def test_forward_parity(gpu_device, P, W, H, f, seed, use_sh, use_cov):
     assert len(keys) == b.num_rendered
     np.testing.assert_array_equal(keys, b.keys_sorted)
     np.testing.assert_array_equal(plist, b.point_list)
+    # duplicate's per-pair tile test: whatever it drops cannot contribute (float64, every pixel of the tile), and it does
+    # drop a substantial share (the blend kernels' lane occupancy depends on it)
+    flags = helpers.LAST_REACH_FLAGS[0]
+    n_dropped = helpers.assert_reach_flags_keep_every_contributor(flags, keys, plist, g, W, H)
+    assert n_dropped > 0.15 * len(plist), (n_dropped, len(plist))
     np.testing.assert_array_equal(ranges, b.ranges)
     # floats: 1e-4
     np.testing.assert_allclose(color.detach().cpu().numpy(), ref["color"], atol=IMG_TOL, rtol=0)
