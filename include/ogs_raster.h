@@ -232,6 +232,9 @@ int ogs_raster_export_binning(const OgsRasterFwdArgs* args, int64_t num_rendered
  * the dominant kernels), enable(0) stops; collect() writes a JSON object
  * {"kernel": {"calls": n, "total_ms": t}, ...} into buf (host memory). */
 int ogs_prof_enable(int on);
+/* mode 2 brackets the kernels whose name starts with `prefix` (default "blend_"; at most 63 characters): a timed
+ * region that only needs the dominant kernel's duration passes that kernel's name. */
+int ogs_prof_filter(const char* prefix);
 int ogs_prof_collect(char* buf, size_t n);
 
 /* Test hook, not part of the reference boundary: runs the wave64 16-slot transposed reduction (mask reductions,

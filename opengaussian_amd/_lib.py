@@ -86,6 +86,7 @@ SIGNATURES = {
     "ogs_selftest_wave_fold16": (C.c_int, [_vp, _vp, _vp]),
     "ogs_selftest_tile_order": (C.c_int, [_vp, C.c_int64, _vp, _vp]),
     "ogs_prof_enable": (C.c_int, [C.c_int]),
+    "ogs_prof_filter": (C.c_int, [C.c_char_p]),
     "ogs_prof_collect": (C.c_int, [C.c_char_p, C.c_size_t]),
     "ogs_kmeans_tmp_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     "ogs_kmeans_lloyd": (C.c_int, [_vp, C.c_int64, C.c_int32, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
@@ -133,6 +134,11 @@ def lib() -> C.CDLL:
 def check(rc: int, what: str):
     if rc != 0:
         raise OgsError(f"{what} failed (code {rc}): {lib().ogs_last_error().decode()}")
+
+
+def prof_filter(prefix: str):
+    """mode 2 of prof_enable brackets the kernels whose name starts with `prefix` (default "blend_")."""
+    check(lib().ogs_prof_filter(prefix.encode()), "ogs_prof_filter")
 
 
 def prof_enable(mode):

@@ -25,7 +25,9 @@ void set_error(const char* fmt, ...) {
 // ---- per-kernel timing ----------------------------------------------------------------------------------
 namespace {
 struct ProfRec { const char* name; hipEvent_t start, stop; };
-int g_prof_mode = 0;     // 0 off, 1 every launch, 2 only the blend kernels (cheap enough for a timed region)
+int g_prof_mode = 0;     // 0 off, 1 every launch, 2 only kernels whose name starts with g_prof_prefix (cheap enough for a
+                         // timed region: "blend_" = both blend kernels, or the one dominant kernel's name)
+char g_prof_prefix[64] = "blend_";
 std::vector<ProfRec> g_prof;
 std::vector<hipEvent_t> g_event_pool;
 std::mutex g_prof_mu;
@@ -39,7 +41,7 @@ hipEvent_t take_event() {
 
 ProfScope::ProfScope(const char* n, hipStream_t s) : name(n), stream(s), slot(-1) {
     if (g_prof_mode == 0) return;
-    if (g_prof_mode == 2 && strncmp(n, "blend_", 6) != 0) return;
+    if (g_prof_mode == 2 && strncmp(n, g_prof_prefix, strlen(g_prof_prefix)) != 0) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfRec r{n, take_event(), take_event()};
     (void)hipEventRecord(r.start, s);
@@ -118,7 +120,7 @@ using namespace ogs;
 
 extern "C" {
 
-int ogs_version(void) { return 200; }
+int ogs_version(void) { return 210; }
 
 /* Per-kernel timing with HIP events recorded on the launch stream (bench.py's `roofline` leg).
  * ogs_prof_enable(1) starts a fresh recording; ogs_prof_collect() waits for the recorded events and
@@ -128,6 +130,13 @@ int ogs_prof_enable(int on) {
     for (auto& r : g_prof) { g_event_pool.push_back(r.start); g_event_pool.push_back(r.stop); }
     g_prof.clear();
     g_prof_mode = on;
+    return OGS_OK;
+}
+
+int ogs_prof_filter(const char* prefix) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!prefix || strlen(prefix) >= sizeof(g_prof_prefix)) { set_error("prof_filter: prefix NULL or longer than %zu", sizeof(g_prof_prefix) - 1); return OGS_ERR_INVALID_ARG; }
+    strcpy(g_prof_prefix, prefix);
     return OGS_OK;
 }
 
