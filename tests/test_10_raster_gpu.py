@@ -506,13 +506,13 @@ def test_adversarial_scenes_forward_and_backward(gpu_device, kind, P, W, H):
               f"{np.abs(got - want).max() / (np.abs(want).max() + 1e-12):.1e} (all rows)")
 
 
-@pytest.mark.parametrize("use_sh,G", [(False, 5), (True, 3), (False, 37)])
-def test_grouped_pass_equals_subset_renders(gpu_device, use_sh, G):
+@pytest.mark.parametrize("use_sh,G,P", [(False, 5, 4000), (True, 3, 4000), (False, 37, 4000), (True, 4, 900)])
+def test_grouped_pass_equals_subset_renders(gpu_device, use_sh, G, P):
     """rasterize_groups (ONE pass, G images) == the reference's per-cluster loop of rasterizer calls on
     boolean-indexed subsets (gaussian_renderer/__init__.py:203-225,327-345): forward bit for bit, gradients up to
     the summation order of the float atomics."""
     from opengaussian_amd.rasterizer import GaussianRasterizer, rasterize_groups
-    P, W, H, f = 4000, 150, 90, 110.0
+    W, H, f = 150, 90, 110.0            # P = 900: the grouped pass itself takes the one-workgroup geometry phase
     sc, cam = helpers.tiny_scene(P, W, H, f, seed=21)
     st = helpers.settings_for(cam, (0.2, 0.1, 0.3), 3, gpu_device)
     g = torch.Generator().manual_seed(3)
