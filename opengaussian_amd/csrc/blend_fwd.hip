@@ -82,11 +82,12 @@ __global__ __launch_bounds__(kBlock) void pack_sorted_kernel(const uint2* __rest
             // blend loops test it with ONE compare |power + h| <= h (opacity <= 0: NaN/-inf, never a candidate)
             h = 0.5f * (__logf(255.0f * b.w) + kThrMargin);
             const float thr = -2.0f * h;
+            const float nbA = -b.y / b.x, nbC = -b.y / b.z;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float qx = X0 + (float)((q & 1) * 8), qy = Y0 + (float)((q >> 1) * 8);
                 // d = centre - pixel, pixel in [qx, qx+7] x [qy, qy+7]
-                const float m = max_power_in_box(b.x, b.y, b.z, a.x - qx - 7.f, a.x - qx, a.y - qy - 7.f, a.y - qy);
+                const float m = max_power_in_box(b.x, b.y, b.z, nbA, nbC, a.x - qx - 7.f, a.x - qx, a.y - qy - 7.f, a.y - qy);
                 if (m >= thr) mask |= 1u << q;
             }
         }

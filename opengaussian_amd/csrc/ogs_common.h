@@ -348,17 +348,21 @@ constexpr float kThrMargin = 0.01f;
 constexpr int kReachBit = 31;                           // Gaussian ids are < 2^31
 constexpr uint32_t kGidMask = (1u << kReachBit) - 1u;
 // max over the box d in [xlo,xhi] x [ylo,yhi] of  -0.5*(A dx^2 + C dy^2) - B dx dy   (A, C > 0, AC - B^2 > 0)
-__device__ __forceinline__ float max_power_in_box(float A, float B, float Cc, float xlo, float xhi, float ylo,
-                                                  float yhi) {
+// nbA = -B / A, nbC = -B / C: the slopes of the 1-D maximisers (per Gaussian, so a caller with many boxes divides once)
+__device__ __forceinline__ float max_power_in_box(float A, float B, float Cc, float nbA, float nbC, float xlo, float xhi,
+                                                  float ylo, float yhi) {
     if (xlo <= 0.f && xhi >= 0.f && ylo <= 0.f && yhi >= 0.f) return 0.f;
     auto q = [&](float dx, float dy) { return -0.5f * (A * dx * dx + Cc * dy * dy) - B * dx * dy; };
-    const float nbA = -B / A, nbC = -B / Cc;
     // concave form, origin outside the box: the maximum sits on an edge, at the clamped 1-D maximiser
     float m = q(xlo, fminf(fmaxf(nbC * xlo, ylo), yhi));
     m = fmaxf(m, q(xhi, fminf(fmaxf(nbC * xhi, ylo), yhi)));
     m = fmaxf(m, q(fminf(fmaxf(nbA * ylo, xlo), xhi), ylo));
     m = fmaxf(m, q(fminf(fmaxf(nbA * yhi, xlo), xhi), yhi));
     return m;
+}
+__device__ __forceinline__ float max_power_in_box(float A, float B, float Cc, float xlo, float xhi, float ylo,
+                                                  float yhi) {
+    return max_power_in_box(A, B, Cc, -B / A, -B / Cc, xlo, xhi, ylo, yhi);
 }
 
 // ---- tiny device helpers ------------------------------------------------------------------------

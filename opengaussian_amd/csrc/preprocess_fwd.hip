@@ -385,13 +385,13 @@ __global__ __launch_bounds__(kBlock) void duplicate_kernel(int P, int W, int H, 
     __shared__ uint32_t s_first, s_total;
     __shared__ uint32_t s_key0[kBlock];     // group * tiles: first virtual tile of the Gaussian's image
     __shared__ float4 s_ctr[kBlock];        // centre x, y, reach threshold (ogs_common.h), conic B
-    __shared__ float2 s_con[kBlock];        // conic A, C
+    __shared__ float4 s_con[kBlock];        // conic A, C, -B / A, -B / C
     const int tid = threadIdx.x;
     const int r = blockIdx.x * kBlock + tid;
     const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
     uint32_t off = 0, cnt = 0, gid = 0, rect = 1u << 24, key0 = 0;
     float4 ctr = make_float4(0.f, 0.f, 0.f, 0.f);
-    float2 con = make_float2(1.f, 1.f);
+    float4 con = make_float4(1.f, 1.f, 0.f, 0.f);
     if (r < P) {
         gid = order[r];
         off = offsets[r];
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(kBlock) void duplicate_kernel(int P, int W, int H, 
         if (radius > 0) {
             const float4 b = rec[(size_t)gid * NV + 1];
             ctr = make_float4(a.x, a.y, -(__logf(255.0f * b.w) + kThrMargin), b.y);
-            con = make_float2(b.x, b.z);
+            con = make_float4(b.x, b.z, -b.y / b.x, -b.y / b.z);
             const float rf = (float)radius;
             auto tr = [](float v) -> int {
                 if (!(fabsf(v) < 3.0e38f)) v = 0.f;
@@ -467,9 +467,9 @@ __global__ __launch_bounds__(kBlock) void duplicate_kernel(int P, int W, int H, 
             // can the Gaussian reach ANY pixel of this tile?  One box test per pair, here, while its geometry sits in
             // LDS: pack_sorted_kernel then gathers records (and tests the four quadrants) only for the pairs that can
             const float4 c = s_ctr[lo];
-            const float2 k = s_con[lo];
+            const float4 k = s_con[lo];
             const float X0 = (float)(tx * kTile), Y0 = (float)(ty * kTile);
-            const float m = max_power_in_box(k.x, c.w, k.y, c.x - X0 - 15.f, c.x - X0, c.y - Y0 - 15.f, c.y - Y0);
+            const float m = max_power_in_box(k.x, c.w, k.y, k.z, k.w, c.x - X0 - 15.f, c.x - X0, c.y - Y0 - 15.f, c.y - Y0);
             vals[o] = g | ((m >= c.z ? 1u : 0u) << kReachBit);
         }
     }
