@@ -616,6 +616,38 @@ def test_sh_degrees_coefficient_counts_and_scale_modifier(gpu_device, sh_degree,
         assert float(leaves["shs"].grad[:, (sh_degree + 1) ** 2:].abs().max()) == 0.0
 
 
+def test_random_configurations_backward_parity(gpu_device):
+    """12 seeded random configurations of the BACKWARD against float64 autograd through the oracle: image sizes that are
+    no multiples of 16, 40 .. 2500 Gaussians (both sides of the one-workgroup geometry phase), footprints from a few
+    pixels to most of the image (many partial batches of the matrix-core reduction, moment shifts over hundreds of
+    pixels), SH / precomputed colours / 6-D features, covariance input, near-threshold opacities."""
+    rng = np.random.default_rng(77)
+    worst = {}
+    for it in range(12):
+        W, H = int(rng.integers(40, 170)), int(rng.integers(30, 120))
+        P = int(rng.choice([40, 300, 900, 1024, 1025, 2500]))
+        f = float(rng.uniform(0.5, 1.4) * max(W, H))
+        lsm = float(rng.uniform(-4.0, -1.2))
+        mode = it % 3                                             # 0: SH colours, 1: 6-D features, 2: SH + cov3D input
+        sc, cam = helpers.tiny_scene(P, W, H, f, seed=4000 + it, log_scale_mean=lsm, with_ties=bool(it % 4 == 0))
+        if it % 4 == 1:
+            sc.opacities[:] = torch.rand_like(sc.opacities) ** 3
+        if mode == 1:
+            inp, bg = helpers.oracle_inputs(sc, cam, feat=sc.ins_feat), (0.0,) * 6
+        else:
+            inp, bg = helpers.oracle_inputs(sc, cam, use_sh=True, use_cov=(mode == 2)), tuple(float(x) for x in rng.uniform(0, 1, 3))
+        tag = f"config {it}: {W}x{H} P={P} f={f:.1f} lsm={lsm:.2f} mode={mode}"
+        try:
+            errs = _grad_check(inp, cam, W, H, f, gpu_device, bg=bg, seed=it)
+        except AssertionError as e:
+            raise AssertionError(f"{tag}: {e}") from None
+        assert errs, tag
+        for k, e in errs.items():
+            assert e < GRAD_TOL, f"{tag}: {k}: relative error {e} (all: {errs})"
+            worst[k] = max(worst.get(k, 0.0), e)
+    print("random backward parity, worst per family:", {k: f"{e:.1e}" for k, e in worst.items()})
+
+
 def test_random_configurations_forward_parity(gpu_device):
     """24 seeded random configurations (image sizes incl. non-multiples of 16 and single-tile images, point counts
     from 1 to a few thousand, focal lengths, scale / opacity statistics, SH or precomputed colours, covariance
