@@ -58,6 +58,14 @@ int ogs_mask_cohesion(const float* feat, const uint8_t* masks, const float* mean
 int ogs_mask_cohesion_backward(const float* feat, const uint8_t* masks, const float* mean, const float* gl, int32_t C,
                                int32_t N, int64_t HW, float* dfeat, float* dmean, void* stream);
 
+/* separation_loss (train.py:124-155), forward AND gradient in two small launches: means [N, C] (2 <= N <= 1024 masks,
+ * C <= 16), late != 0 for iteration > 35 000 (weights below 0.9 become 0.1).  loss[0] = sum_ij inv_ij * w_ij / (N (N-1))
+ * with inv_ij = 1 / (|m_i - m_j|^2 + 1), 0 on the diagonal, and w_ij = rank of inv_ij inside row i (ties by column, i.e.
+ * a stable argsort().argsort()) / (N-1) * 0.9 + 0.1.  grad ([N, C], may be NULL) = dloss/dmeans; the rank weights carry no
+ * gradient, as under autograd.  tmp: (N * N + N) floats of device scratch. */
+int ogs_separation_loss(const float* means, int32_t N, int32_t C, int32_t late, float* loss, float* grad, float* tmp,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -96,6 +96,7 @@ SIGNATURES = {
     "ogs_mask_feature_sums_backward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int64, _vp, _vp, _vp]),
     "ogs_mask_cohesion": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int64, _vp, _vp]),
     "ogs_mask_cohesion_backward": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int64, _vp, _vp, _vp]),
+    "ogs_separation_loss": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
     "ogs_adam_step": (C.c_int, [C.POINTER(OgsAdamTensor), C.c_int32, C.c_double, C.c_double, C.c_double, _vp]),
     "ogs_rows_gather": (C.c_int, [C.POINTER(OgsRowTensor), C.c_int32, _vp, _vp, C.c_int64, _vp]),
     "ogs_densify_tmp_bytes": (C.c_size_t, [C.c_int32]),

@@ -278,6 +278,88 @@ using namespace ogs;
         else        { if (vec) { CALL(3, true); } else { CALL(3, false); } } \
     } while (0)
 
+// ---- separation_loss (train.py:124-155): [N, N] work on the mask means ------------------------------------------------
+// In torch this is ~30 launch-bound little kernels plus two segmented sorts (argsort().argsort() = the rank of every
+// element inside its row): 0.3-0.45 ms forward + backward for N = 32..200 masks, as much as a quarter of a stage-1
+// iteration.  Here: one workgroup per row i computes inv[i][j] = 1 / (|m_i - m_j|^2 + 1) (0 on the diagonal) into
+// LDS, ranks every element inside the row by counting (ties by column index, i.e. a stable sort), applies the
+// rank weight and leaves the row's partial loss and its weights; a second launch sums the rows in index order and
+// forms the gradient  dL/dm_i = -2 / (N (N-1)) * sum_j (w_ij + w_ji) * inv_ij^2 * (m_i - m_j)  (the weights come from
+// sort indices and carry no gradient, as in autograd).
+constexpr int kSepMaxN = 1024, kSepMaxC = 16;
+__global__ __launch_bounds__(kBlock) void separation_rows_kernel(const float* __restrict__ means, int N, int C, int late,
+                                                                 float* __restrict__ weights, float* __restrict__ row_loss) {
+    __shared__ float s_inv[kSepMaxN];
+    __shared__ float s_mi[kSepMaxC];
+    __shared__ float s_part[kBlock];
+    const int i = blockIdx.x, tid = threadIdx.x;
+    if (tid < C) s_mi[tid] = means[(size_t)i * C + tid];
+    __syncthreads();
+    for (int j = tid; j < N; j += kBlock) {
+        float d2 = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float d = s_mi[c] - means[(size_t)j * C + c];
+            d2 = __fadd_rn(d2, __fmul_rn(d, d));            // pow(2) then sum(2): no contraction
+        }
+        s_inv[j] = j == i ? 0.f : 1.0f / (d2 + 1.0f);
+    }
+    __syncthreads();
+    float part = 0.f;
+    for (int j = tid; j < N; j += kBlock) {
+        const float v = s_inv[j];
+        int rank = 0;
+        for (int k = 0; k < N; ++k) {
+            const float u = s_inv[k];                          // wave-uniform address: broadcast read
+            rank += (u < v || (u == v && k < j)) ? 1 : 0;
+        }
+        float w = __fadd_rn(__fmul_rn((float)rank / (float)(N - 1), 0.9f), 0.1f);   // (rank / (N-1)) * (1.0 - 0.1) + 0.1
+        if (late && w < 0.9f) w = 0.1f;                         // iteration > 35 000 (train.py:148-149)
+        weights[(size_t)i * N + j] = w;
+        part = __fadd_rn(part, __fmul_rn(v, w));
+    }
+    s_part[tid] = part;
+    __syncthreads();
+    for (int st = kBlock / 2; st >= 1; st >>= 1) {              // fixed-order tree: deterministic
+        if (tid < st) s_part[tid] += s_part[tid + st];
+        __syncthreads();
+    }
+    if (tid == 0) row_loss[i] = s_part[0];
+}
+
+__global__ __launch_bounds__(kBlock) void separation_finish_kernel(const float* __restrict__ means, int N, int C,
+                                                                   const float* __restrict__ weights,
+                                                                   const float* __restrict__ row_loss,
+                                                                   float* __restrict__ loss_out, float* __restrict__ grad) {
+    const float scale = 1.0f / ((float)N * (float)(N - 1));
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float t = 0.f;
+        for (int r = 0; r < N; ++r) t += row_loss[r];           // rows in index order
+        loss_out[0] = t * scale;
+    }
+    if (!grad) return;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= N) return;
+    float mi[kSepMaxC], g[kSepMaxC];
+#pragma unroll
+    for (int c = 0; c < kSepMaxC; ++c) { mi[c] = c < C ? means[(size_t)i * C + c] : 0.f; g[c] = 0.f; }
+    for (int j = 0; j < N; ++j) {
+        if (j == i) continue;
+        float d[kSepMaxC], d2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < kSepMaxC; ++c) {
+            d[c] = c < C ? mi[c] - means[(size_t)j * C + c] : 0.f;
+            d2 += d[c] * d[c];
+        }
+        const float inv = 1.0f / (d2 + 1.0f);
+        const float k = (weights[(size_t)i * N + j] + weights[(size_t)j * N + i]) * inv * inv;
+#pragma unroll
+        for (int c = 0; c < kSepMaxC; ++c) g[c] += k * d[c];
+    }
+#pragma unroll
+    for (int c = 0; c < kSepMaxC; ++c)
+        if (c < C) grad[(size_t)i * C + c] = -2.0f * scale * g[c];
+}
+
 extern "C" {
 
 int ogs_mask_feature_sums(const float* feat, const uint8_t* masks, const float* weight, int32_t C, int32_t N, int64_t HW,
@@ -364,6 +446,23 @@ int ogs_mask_cohesion_backward(const float* feat, const uint8_t* masks, const fl
                N, HW, dfeat, dmean)
     OGS_MASK_DISPATCH(CALL);
 #undef CALL
+    OGS_LAUNCH_CHECK(0, s);
+    return OGS_OK;
+}
+
+int ogs_separation_loss(const float* means, int32_t N, int32_t C, int32_t late, float* loss, float* grad, float* tmp,
+                        void* stream_) {
+    if (N < 2 || N > kSepMaxN || C < 1 || C > kSepMaxC) {
+        set_error("separation_loss: N=%d (2..%d), C=%d (1..%d)", N, kSepMaxN, C, kSepMaxC); return OGS_ERR_UNSUPPORTED;
+    }
+    if (!means || !loss || !tmp) { set_error("separation_loss: NULL pointer"); return OGS_ERR_INVALID_ARG; }
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    float* weights = tmp;                        // [N, N]
+    float* row_loss = tmp + (size_t)N * N;       // [N]
+    OGS_LAUNCH(separation_rows_kernel, dim3(N), dim3(kBlock), 0, s, means, N, C, late, weights, row_loss);
+    OGS_LAUNCH_CHECK(0, s);
+    OGS_LAUNCH(separation_finish_kernel, dim3((N + kBlock - 1) / kBlock), dim3(kBlock), 0, s, means, N, C,
+               (const float*)weights, (const float*)row_loss, loss, grad);
     OGS_LAUNCH_CHECK(0, s);
     return OGS_OK;
 }

@@ -114,3 +114,35 @@ def test_edge_cases(gpu_device):
     mu = mk.mask_feature_mean(const, one)
     mk.cohesion_loss(const, one, mu).backward()
     assert torch.isfinite(const.grad).all() and float(const.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("N,Cc", [(2, 6), (32, 6), (96, 6), (200, 3), (257, 9)])
+def test_separation_loss_fused_equals_torch_formulation(gpu_device, N, Cc):
+    """ogs_separation_loss (two launches: pairwise inverse distances, rank of every element inside its row, rank
+    weights, sum and gradient) against the literal torch formulation of train.py:124-155 (argsort().argsort()), early
+    and late (iteration > 35 000) weights, value and gradient; and the degenerate case of identical rows (empty masks
+    share the zero mean: exact ties, where the reference's unstable argsort is implementation defined)."""
+    from opengaussian_amd import mask_ops as mk
+    g = torch.Generator().manual_seed(100 + N)
+    base = torch.rand(N, Cc, generator=g)
+    for it in (1000, 40000):
+        a = base.clone().to(gpu_device).requires_grad_(True)
+        b = base.clone().to(gpu_device).requires_grad_(True)
+        la = mk.separation_loss(a, it)
+        lb = mk._separation_loss_torch(b, it)
+        (la * 3.0).backward()
+        (lb * 3.0).backward()
+        torch.testing.assert_close(la.detach(), lb.detach(), rtol=2e-6, atol=1e-7)
+        # every gradient element is a sum of N signed terms: compare at the scale of the largest one.  Two inverse
+        # distances of a row that differ in the last bit may swap ranks between the two evaluations of |m_i - m_j|^2
+        # (a near-tie decision, as in k-means): that moves ONE weight pair by 0.9 / (N-1), i.e. a gradient element by at
+        # most 2 * 2 * 0.9 / (N-1) / (N (N-1)) * max |d| inv^2 <= 3.6 / ((N-1)^2 N) -- allowed once per element
+        flip = 3.6 / ((N - 1) ** 2 * N)
+        assert float((a.grad - b.grad).abs().max()) <= 1e-5 * float(b.grad.abs().max()) + flip
+        # no gradient requested: value only
+        assert float(mk.separation_loss(base.to(gpu_device), it)) == float(la.detach())
+    tied = base.clone()
+    tied[: N // 2] = 0.0                                   # identical rows
+    t1 = mk.separation_loss(tied.to(gpu_device).requires_grad_(True), 1000)
+    t2 = mk.separation_loss(tied.to(gpu_device).requires_grad_(True), 1000)
+    assert torch.isfinite(t1) and float(t1.detach()) == float(t2.detach())   # deterministic, stable tie-breaking
