@@ -330,19 +330,21 @@ __global__ __launch_bounds__(kBlock) void separation_finish_kernel(const float* 
                                                                    const float* __restrict__ weights,
                                                                    const float* __restrict__ row_loss,
                                                                    float* __restrict__ loss_out, float* __restrict__ grad) {
+    // one workgroup per row i: thread j owns the pairs (i, j), (i, j + 256), ...; per-channel sums leave the workgroup
+    // through a wave butterfly and four LDS slots (fixed order: deterministic)
+    __shared__ float s_g[kBlock / kWave][kSepMaxC];
     const float scale = 1.0f / ((float)N * (float)(N - 1));
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const int i = blockIdx.x, tid = threadIdx.x;
+    if (i == 0 && tid == 0) {
         float t = 0.f;
         for (int r = 0; r < N; ++r) t += row_loss[r];           // rows in index order
         loss_out[0] = t * scale;
     }
     if (!grad) return;
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= N) return;
     float mi[kSepMaxC], g[kSepMaxC];
 #pragma unroll
     for (int c = 0; c < kSepMaxC; ++c) { mi[c] = c < C ? means[(size_t)i * C + c] : 0.f; g[c] = 0.f; }
-    for (int j = 0; j < N; ++j) {
+    for (int j = tid; j < N; j += kBlock) {
         if (j == i) continue;
         float d[kSepMaxC], d2 = 0.f;
 #pragma unroll
@@ -356,8 +358,21 @@ __global__ __launch_bounds__(kBlock) void separation_finish_kernel(const float* 
         for (int c = 0; c < kSepMaxC; ++c) g[c] += k * d[c];
     }
 #pragma unroll
-    for (int c = 0; c < kSepMaxC; ++c)
-        if (c < C) grad[(size_t)i * C + c] = -2.0f * scale * g[c];
+    for (int c = 0; c < kSepMaxC; ++c) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) g[c] += __shfl_xor(g[c], o, kWave);
+    }
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int c = 0; c < kSepMaxC; ++c) s_g[tid >> 6][c] = g[c];
+    }
+    __syncthreads();
+    if (tid < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < kBlock / kWave; ++w) t += s_g[w][tid];
+        grad[(size_t)i * C + tid] = -2.0f * scale * t;
+    }
 }
 
 extern "C" {
@@ -461,7 +476,7 @@ int ogs_separation_loss(const float* means, int32_t N, int32_t C, int32_t late, 
     float* row_loss = tmp + (size_t)N * N;       // [N]
     OGS_LAUNCH(separation_rows_kernel, dim3(N), dim3(kBlock), 0, s, means, N, C, late, weights, row_loss);
     OGS_LAUNCH_CHECK(0, s);
-    OGS_LAUNCH(separation_finish_kernel, dim3((N + kBlock - 1) / kBlock), dim3(kBlock), 0, s, means, N, C,
+    OGS_LAUNCH(separation_finish_kernel, dim3(grad ? N : 1), dim3(kBlock), 0, s, means, N, C,
                (const float*)weights, (const float*)row_loss, loss, grad);
     OGS_LAUNCH_CHECK(0, s);
     return OGS_OK;
