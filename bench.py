@@ -238,9 +238,41 @@ def log(msg):
     sys.stderr.flush()
 
 
+def self_launch(args) -> int:
+    """`python3 bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): start the N ranks ourselves.
+
+    The parent never touches the GPU (nothing below initialises HIP; `import torch` alone does not): it runs
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>
+    bench.py <same arguments>` as a CHILD process (no exec), relays rank 0's JSON line on stdout and returns the
+    children's return code.  Under the driver's own torchrun command WORLD_SIZE is set and this is skipped."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    log("self-launch: " + " ".join(cmd))
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)       # stderr is inherited (progress lines)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    js = [ln for ln in lines if ln.lstrip().startswith("{")]
+    for ln in (js[-1:] if js else lines):
+        print(ln)
+    sys.stdout.flush()
+    if r.returncode == 0 and not js:
+        log("self-launch: the ranks exited 0 but printed no JSON line")
+        return 1
+    return r.returncode
+
+
 def main():
     args = parse()
     log("start")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     from opengaussian_amd import _lib, dp
     from opengaussian_amd import rasterizer as R
     from opengaussian_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_fused
@@ -276,7 +308,7 @@ def main():
     all_settings = [settings_of(c) for c in cams_cpu]
     campos_views = torch.stack([c.camera_center for c in cams_cpu]).to(device)
     dist_on = world > 1 or dp.FORCE_COLLECTIVES
-    info = {"i": 0, "D_seen": []}
+    info = {"i": 0, "D_seen": [], "xmode": args.exchange}
 
     def view_of(step_index, r):
         return (step_index * world + r) % V
@@ -301,7 +333,7 @@ def main():
     # ogs_sh_grad_from_views: 4x fewer xGMI bytes than all-reducing [P,16,3]), and a MAX all-reduce of the radii.
     compress_sh = dist_on and fused and not args.dense_sh_allreduce
     names_x = [n for n in names_f if not (compress_sh and n == "shs")]
-    nsets = 2 if args.exchange == "pipelined" else 1
+    nsets = 2                                     # double-buffered; 'sync' / 'none' use set 0 / nothing
     sets = []
     if dist_on and fused:
         for _ in range(nsets):
@@ -338,8 +370,9 @@ def main():
         info["D"] = color.grad_fn.num_rendered
         info["D_seen"].append(info["D"])
         torch.autograd.backward([color, alpha], [gCF, gA])
-        if sets:
-            st = sets[i % nsets]
+        xmode = info["xmode"]
+        if sets and xmode != "none":
+            st = sets[i % nsets] if xmode == "pipelined" else sets[0]
             st["campos"] = campos_views[[view_of(i, r) for r in range(world)]]
             st["bucket"].pack([leaves[n].grad for n in names_x] + [dp.densification_stats(m2.grad, radii)])
             st["bucket"].allreduce_async()                               # RCCL, side stream
@@ -349,7 +382,7 @@ def main():
             st["pending"] = True
             # pipelined: this step's exchange keeps running while the NEXT render is enqueued; the previous
             # step's exchange (which overlapped this render) is completed now
-            finish(sets[(i - 1) % nsets] if nsets == 2 else st)
+            finish(sets[(i - 1) % nsets] if xmode == "pipelined" else st)
         return radii
 
     def drain():
@@ -446,6 +479,58 @@ def main():
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
+    # N > 1, untimed extras: the same steps with each step waiting for its own exchange ('sync') and with no exchange at
+    # all ('none') -> how much of the exchange the pipelined mode leaves exposed (barrier + max over ranks, as above)
+    xtimes = {}
+    if dist_on and fused and not args.no_extras:
+        nb = max(2, min(args.steps, 20))
+        for mode in [m for m in ("pipelined", "sync", "none") if m != args.exchange]:
+            info["xmode"] = mode
+            for _ in range(2):
+                step()
+            drain()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(nb):
+                step()
+            drain()
+            torch.cuda.synchronize()
+            barrier()
+            tm = torch.tensor([(time.perf_counter() - t1) / nb * 1e3], device=device, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            xtimes[mode] = float(tm.item())
+        info["xmode"] = args.exchange
+        log(f"exchange modes (ms/step): {xtimes}")
+    # who took part: every rank reports its device, gathered to rank 0 (lets a reader verify that N ranks on N
+    # devices really ran under the backend named)
+    dist_info = None
+    if dist_on:
+        prop = torch.cuda.get_device_properties(device)
+        mine = {"rank": rank, "local_rank": local, "pid": os.getpid(), "cuda_device": torch.cuda.current_device(),
+                "device_name": prop.name, "pci_bus_id": getattr(prop, "pci_bus_id", None),
+                "uuid": str(getattr(prop, "uuid", "")) or None}
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        xbytes = 0
+        if sets:
+            xbytes = sets[0]["bucket"].flat.numel() * 4 + P * 4
+            if sets[0]["sh"] is not None:
+                xbytes += world * P * 3 * 4
+        dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": everyone,
+                     "devices_visible_per_rank": torch.cuda.device_count(),
+                     "exchange_mode_timed": args.exchange,
+                     "exchange_bytes_per_step_per_rank": xbytes,
+                     "exchange_messages": ("flat SUM all-reduce %d B + all-gather of the [P,3] SH-gradient factor %d B "
+                                           "per rank + int32 MAX all-reduce %d B" %
+                                           (sets[0]["bucket"].flat.numel() * 4,
+                                            P * 12 if sets[0]["sh"] is not None else 0, P * 4)) if sets else None,
+                     "ms_per_step_by_exchange_mode": {args.exchange: elapsed / args.steps * 1e3, **xtimes},
+                     "exposed_exchange_ms_per_step": (elapsed / args.steps * 1e3 - xtimes["none"]) if "none" in xtimes else None,
+                     "sync_minus_pipelined_ms_per_step": ((xtimes.get("sync", elapsed / args.steps * 1e3) -
+                                                          xtimes.get("pipelined", elapsed / args.steps * 1e3))
+                                                         if xtimes else None)}
+
     ms_per_step = elapsed / args.steps * 1e3
     value = world * W * H * args.steps / elapsed / 1e6
 
@@ -529,6 +614,7 @@ def main():
             # how the render phase was sized during the timed steps: sync-free (capacity hint) vs blocking read-back
             # vs overflow (render phase enqueued twice); the timed value pays for every one of them
             "render_phase_sizing_timed": {k: stats_timed[k] - stats0[k] for k in stats_timed},
+            "dist": dist_info,
             "roofline": roofline,
             "roofline_valu": valu,
             "pmc_hbm_rate_per_kernel": hbm_kernels,

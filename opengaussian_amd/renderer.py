@@ -58,7 +58,9 @@ def _knn_mean_filter(points: torch.Tensor) -> torch.Tensor:
     neighbours (self included, as pytorch3d.ops.knn_points(x, x) returns it) below mean + std."""
     n = points.shape[0]
     K = max(1, int(n ** 0.5))
-    d2 = torch.cdist(points, points) ** 2
+    # direct differences, as pytorch3d's kernel computes them (the default cdist goes through a matmul for > 25 rows and
+    # loses ~1e-4 absolute on squared distances of ~1e-3 by cancellation)
+    d2 = torch.cdist(points, points, compute_mode="donot_use_mm_for_euclid_dist") ** 2
     knn = torch.topk(d2, K, dim=1, largest=False).values
     return knn.mean(dim=-1) < knn.mean() + knn.std()
 
@@ -226,6 +228,8 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, iteration,
         if better_vis:
             # every coarse cluster, small Gaussians only, at least 100 of them (:186-189)
             gid = torch.where((scales < 0.5).all(dim=1), gid, none_of(gid))
+        elif selected_root_id is None:
+            gid = none_of(gid)          # `idx != None` holds for every idx: the reference skips every cluster (:180-181)
         else:
             gid = torch.where(gid == selected_root_id, gid, none_of(gid))       # the selected one only (:180-181)
         if viewpoint_camera.bClusterOccur is not None:                           # clusters this camera never sees (:182-183)

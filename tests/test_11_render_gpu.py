@@ -231,3 +231,85 @@ def test_batched_cluster_loops_equal_per_subset_calls(gpu_device, mode):
             continue
         scale = float(lb.grad.abs().max()) + 1e-20
         assert float((la.grad - lb.grad).abs().max()) / scale < 5e-4, name
+
+
+# ---- render() against fixtures produced by RUNNING the reference's own render() over the CPU oracle -------------------
+# tests/golden/make_render_golden.py (build container only) -> tests/golden/render_golden.npz; inputs are rebuilt from the
+# seeds by tests/golden/render_cases.py on both sides.  Images 1e-4 (depth 1e-3, un-normalised sum of z * w), integers and
+# list structure exact, gradients 2e-4 of the family's largest entry AND 2e-2 relative on every row above 1 % of it.
+def _golden():
+    import os
+    import numpy as np
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "render_golden.npz"))
+
+
+def _render_case_names():
+    from tests.golden import render_cases as rc
+    return list(rc.CASES)
+
+
+@pytest.mark.parametrize("name", _render_case_names())
+def test_render_matches_reference_run_fixture(gpu_device, name):
+    import numpy as np
+    from opengaussian_amd.renderer import render
+    from tests.golden import render_cases as rc
+    dev = gpu_device
+    gold = _golden()
+    case = rc.build(name)
+    has = lambda k: f"{name}/{k}" in gold.files
+    want = lambda k: gold[f"{name}/{k}"]
+    pc = rc.TinyModel(case["params"], dev, requires_grad=case["grads"])
+    cam = case["cam"].to(dev)
+    if cam.bClusterOccur is not None:
+        cam.bClusterOccur = cam.bClusterOccur.to(dev)
+    kwargs = rc.move_kwargs(case["kwargs"], dev)
+    torch.manual_seed(case["rng_seed"])                     # the reference's global-RNG draws (:121-124), replayed
+    with (torch.enable_grad() if case["grads"] else torch.no_grad()):
+        out = render(cam, pc, case["pipe"], case["bg"].to(dev), 1, **kwargs)
+        loss = rc.fixed_loss(out) if case["grads"] else None
+        if loss is not None:
+            loss.backward()
+    assert list(out) == ["render", "alpha", "depth", "silhouette", "ins_feat", "cluster_imgs", "cluster_silhouettes",
+                         "leaf_clusters_imgs", "leaf_cluster_silhouettes", "occured_leaf_id", "cluster_occur",
+                         "viewspace_points", "visibility_filter", "radii"]
+    # integers, masks, ids: exact
+    assert np.array_equal(out["radii"].cpu().numpy(), want("radii"))
+    assert np.array_equal(out["visibility_filter"].cpu().numpy(), want("visibility_filter"))
+    assert tuple(out["viewspace_points"].shape) == tuple(want("viewspace_points_shape"))
+    if has("cluster_occur/none"):
+        assert out["cluster_occur"] is None
+    else:
+        assert np.array_equal(out["cluster_occur"].cpu().numpy(), want("cluster_occur"))
+    if has("occured_leaf_id/none"):
+        assert out["occured_leaf_id"] is None
+    else:
+        assert [int(x) for x in out["occured_leaf_id"]] == want("occured_leaf_id").tolist()
+    # images
+    for k in rc.TENSOR_KEYS:
+        v = out[k]
+        if has(f"{k}/none"):
+            assert v is None, k
+        elif has(f"{k}/emptylist"):
+            assert isinstance(v, list) and len(v) == 0, k
+        else:
+            assert tuple(v.shape) == want(k).shape, k
+            helpers.assert_close_modulo_threshold_flips(v.detach().cpu().numpy(), want(k), tol=1e-3 if k == "depth" else 1e-4,
+                                                        flip_tol=4e-2 if k == "depth" else 4e-3)
+    for k in rc.LIST_KEYS:
+        v = out[k]
+        if has(f"{k}/none"):
+            assert v is None, k
+            continue
+        assert isinstance(v, list) and len(v) == int(want(f"{k}/len")), k
+        for i, img in enumerate(v):
+            assert tuple(img.shape) == want(f"{k}/{i}").shape
+            helpers.assert_close_modulo_threshold_flips(img.detach().cpu().numpy(), want(f"{k}/{i}"))
+    # gradients of the fixed loss through the whole call
+    if case["grads"]:
+        assert abs(float(loss.detach()) - float(want("loss"))) <= 2e-4 * max(1.0, abs(float(want("loss"))))
+        fam = {n: getattr(pc, n).grad for n in rc.PARAM_NAMES}
+        fam["viewspace_points"] = out["viewspace_points"].grad
+        for n, g in fam.items():
+            w = want(f"grad/{n}").astype(np.float64)
+            got = np.zeros_like(w) if g is None else g.detach().cpu().double().numpy()
+            helpers.assert_grad_family_close(got, w, what=f"{name}:{n}")

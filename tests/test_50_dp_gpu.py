@@ -338,3 +338,33 @@ def test_bench_under_torchrun_one_rank(gpu_device):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["value"] > 0 and "RCCL" in out["config"]["parallelism"], out["config"]
+
+
+def test_bench_self_launches_two_ranks(gpu_device):
+    """`python3 bench.py --gpus 2 ...` invoked DIRECTLY (the driver's N = 1 command form, no launcher, WORLD_SIZE unset):
+    the parent starts the two ranks itself before any GPU call, relays rank 0's JSON line and returns the children's
+    return code.  On the one-GPU test box both ranks share cuda:0, so the collectives go over
+    gloo (OGS_DIST_BACKEND); on the 8-GPU node the same command runs over RCCL."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OGS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "OGS_DP_FORCE_COLLECTIVES"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--workload", "C2-100k-800", "--no-cpu-baseline", "--no-kmeans"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines                                     # ONE JSON line, nothing else on stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0
+    d = out["dist"]
+    assert d["backend"] == "gloo" and d["world_size"] == 2
+    assert sorted(x["rank"] for x in d["ranks"]) == [0, 1]
+    assert len({x["pid"] for x in d["ranks"]}) == 2                   # two processes really ran
+    assert d["exchange_bytes_per_step_per_rank"] > 0
+    modes = d["ms_per_step_by_exchange_mode"]
+    assert set(modes) == {"pipelined", "sync", "none"} and all(v > 0 for v in modes.values())
+    assert d["exposed_exchange_ms_per_step"] is not None

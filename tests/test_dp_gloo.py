@@ -130,3 +130,38 @@ def test_sh_factor_all_gather_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_bench_self_launch_builds_a_torchrun_child_and_never_touches_the_gpu(monkeypatch, capsys):
+    """bench.py --gpus N > 1 with WORLD_SIZE unset: the parent must start `python -m torch.distributed.run
+    --nproc-per-node N bench.py <same args>` as a CHILD (subprocess, no exec), relay the JSON line and return its
+    code -- without initialising the GPU itself (checked here by making any CUDA init raise)."""
+    import importlib.util
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_run(cmd, **kw):
+        seen["cmd"], seen["kw"] = cmd, kw
+        return subprocess.CompletedProcess(cmd, 3, stdout='noise\n{"metric": "m", "n_gpus": 4}\n')
+
+    def boom(*a, **k):
+        raise AssertionError("the self-launching parent touched the GPU")
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(torch.cuda, "is_available", boom)
+    monkeypatch.setattr(torch.cuda, "_lazy_init", boom)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2", "--warmup", "1"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 3                                          # the children's return code
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd
+    i = cmd.index(os.path.join(root, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "2", "--warmup", "1"]
+    assert capsys.readouterr().out.strip() == '{"metric": "m", "n_gpus": 4}'
