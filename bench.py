@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tile-stride", type=int, default=8, help="CPU baseline renders this many full tile rows")
     ap.add_argument("--no-kmeans", action="store_true")
+    ap.add_argument("--no-extra-workloads", action="store_true",
+                    help="skip the C2 / C3 / C4 lines (`extras` in the JSON: the other single-GPU configs of BASELINE.json, each "
+                         "measured by a child run of this script after the headline)")
     ap.add_argument("--rgb-only", action="store_true", help="time pass A only (BASELINE.md row 'RGB')")
     ap.add_argument("--exchange", default="pipelined", choices=["pipelined", "sync"],
                     help="N > 1: 'pipelined' = the gradient exchange of view i overlaps the render of view i+1 on the "
@@ -76,6 +79,7 @@ def parse():
 WORKLOADS = {
     "S1M-1080p": dict(P=1_000_000, W=1920, H=1080, f=1000.0),
     "C2-100k-800": dict(P=100_000, W=800, H=800, f=700.0),
+    "C3-500k-988": dict(P=500_000, W=988, H=731, f=800.0),      # LeRF-teatime-class image and point count
     "C4-2M-648": dict(P=2_000_000, W=648, H=484, f=500.0),      # ScanNet-class: many Gaussians, small image
 }
 
@@ -227,6 +231,32 @@ def stage1_bench(leaves, all_settings, gF, P, device, reps=40):
     W, H = gF.shape[2], gF.shape[1]
     return {"ms_per_step": dt * 1e3, "Mpix_per_s": W * H / dt / 1e6,
             "kernels_ms": {k: v["total_ms"] / v["calls"] for k, v in prof.items() if "backward" in k or "blend" in k}}
+
+
+def extra_workloads(args):
+    """The other single-GPU configurations of BASELINE.json (C2 100 k / 800x800, C3-class 500 k / 988x731, C4-class 2 M /
+    648x484), same fused 9-channel fwd+bwd step: each is a CHILD run of this script (fresh process, this process keeps its
+    scene resident but launches nothing meanwhile); reported: ms/step, Mpix/s, the kernel sum of the per-launch breakdown
+    (HIP events around every launch inflate sub-10-us kernels) and the HBM roofline of its dominant kernel."""
+    import subprocess
+    res = {}
+    for wl, key in (("C2-100k-800", "C2"), ("C3-500k-988", "C3"), ("C4-2M-648", "C4")):
+        log(f"extra workload {wl}")
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", wl, "--steps", "100", "--warmup", "10",
+               "--views", str(args.views), "--no-cpu-baseline", "--no-kmeans", "--no-extra-workloads"]
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=600)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+            d = json.loads(line)
+            res[key] = {"workload": d["config"]["workload"], "ms_per_step": d["ms_per_step"], "Mpix_per_s": d["value"],
+                        "kernel_sum_ms": sum(d["kernels_ms_per_step"].values()),
+                        "D_num_rendered": d["scene"]["D_num_rendered"], "mean_tile_list": d["scene"]["mean_tile_list"],
+                        "roofline": d["roofline"], "step_algorithmic_GBps": d["step_algorithmic_GBps"],
+                        "stage1_ms_per_step": (d.get("stage1_pass") or {}).get("ms_per_step"),
+                        "render_phase_sizing_timed": d["render_phase_sizing_timed"]}
+        except Exception as e:          # an extra line never takes the headline down
+            res[key] = {"error": repr(e)}
+    return res
 
 
 _T0 = time.time()
@@ -638,6 +668,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(scene_cpu, cam_cpu, W, H, f, args.cpu_tile_stride, args.rgb_only)
             if "kmeans" in out and "error" not in out["kmeans"]:
                 out["kmeans"]["cpu_baseline"] = kmeans_cpu_baseline()
+        if world == 1 and args.workload == "S1M-1080p" and not args.no_extras and not args.no_extra_workloads:
+            out["extras"] = extra_workloads(args)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -7,12 +7,16 @@
 // ONCE (4 passes over P), duplicates are emitted in that order, and a STABLE sort on the tile id alone
 // (ceil(log2 T / 8) = 2 passes over D at 1080p) yields bit-identical order: depth ascending inside a
 // tile, ties by Gaussian index.  ~3x less sort traffic on the dominant D term.
+#include <stdlib.h>
+#include <string.h>
+
 #include "ogs_common.h"
 
 namespace ogs {
 
 namespace {
 
+constexpr size_t kSweepHeaderWords = 4 * 256 + 4 + 60;     // digit histograms, tickets, error word (+ pad)
 constexpr int kScanItems = 8;
 constexpr int kScanTile = kBlock * kScanItems;   // 2048 elements per workgroup
 
@@ -276,6 +280,178 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint32_t* _
     }
 }
 
+// ---- one launch per pass: decoupled look-back ("onesweep") ------------------------------------------------------
+// The three launches of a pass above (per-workgroup histogram table, row scan, scatter) read the keys twice and cost
+// ~3 x 5 us of dependent launch latency -- on a 100 k-Gaussian scene the 18 radix launches were 37 % of a whole
+// fwd+bwd step (profiles/r03_*).  Here the digit histograms of ALL passes of a sort are taken in one read of the keys
+// (radix_hist_all_kernel: a permutation does not change them) and each pass is ONE launch: a workgroup ranks its tile,
+// publishes its per-digit counts and finds the counts of the tiles before it by decoupled look-back over the
+// status table.
+//   * status word = (flag << 30) | count, flag 1 = this tile's count, 2 = inclusive count of tiles 0..this; ONE 4-byte
+//     granule written by one agent-scope atomic store and polled with agent-scope atomic loads (sc1: MI355X guide,
+//     "Inter-workgroup communication" -- the count travels IN the flagged word, nothing else is handed off);
+//   * the tile a workgroup processes is a TICKET drawn at its start, never blockIdx: a workgroup only ever waits for
+//     smaller tickets, whose workgroups have already started (HIP promises no dispatch order), and they publish before
+//     they wait -- so every wait ends; each spin is bounded all the same (kSpinLimit -> err flag, garbage out, no hang);
+//   * stability: ticket order == memory order of the tiles, ranks inside a tile as in radix_scatter_kernel.
+constexpr uint32_t kStatAgg = 1u << 30, kStatInc = 2u << 30, kStatMask = (1u << 30) - 1u;
+constexpr int kSpinLimit = 1 << 22;
+constexpr int kLookBack = 8;
+constexpr int kHistAllBlocks = 256;          // few, fat workgroups: each flushes <= 4 x 256 global atomics
+
+struct RadixPlanDev { int npass; int shift[4]; int bits[4]; };
+
+__global__ __launch_bounds__(kBlock) void radix_hist_all_kernel(const uint32_t* __restrict__ keys, int64_t n_cap,
+                                                                const uint32_t* __restrict__ n_dev, RadixPlanDev plan,
+                                                                uint32_t* __restrict__ ghist /*[4][256]*/) {
+    __shared__ uint32_t h[4][256];
+    const int64_t n = n_dev ? min((int64_t)*n_dev, n_cap) : n_cap;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) h[p][threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * kBlock) {
+        const uint32_t k = keys[idx];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            if (p < plan.npass) atomicAdd(&h[p][(k >> plan.shift[p]) & ((1u << plan.bits[p]) - 1u)], 1u);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+        if (p < plan.npass && h[p][threadIdx.x] != 0) atomicAdd(&ghist[p * 256 + threadIdx.x], h[p][threadIdx.x]);
+}
+
+template <int ITEMS>
+__global__ __launch_bounds__(kBlock) void radix_onesweep_kernel(const uint32_t* __restrict__ keys_in,
+                                                                const uint32_t* __restrict__ vals_in,
+                                                                uint32_t* __restrict__ keys_out,
+                                                                uint32_t* __restrict__ vals_out, int64_t n_cap,
+                                                                const uint32_t* __restrict__ n_dev, int shift, int bits,
+                                                                const uint32_t* __restrict__ ghist /*[256], this pass*/,
+                                                                uint32_t* __restrict__ status /*[tiles][256], zeroed*/,
+                                                                uint32_t* __restrict__ ticket /*zeroed*/,
+                                                                uint32_t* __restrict__ err) {
+    __shared__ uint32_t wave_hist_s[kBlock / kWave][256];
+    __shared__ uint32_t scan_sums[4];
+    __shared__ uint32_t dig_start[256], glob_base[256];
+    __shared__ uint32_t stage_k[kBlock * ITEMS], stage_v[kBlock * ITEMS];
+    __shared__ uint32_t s_ticket;
+    volatile uint32_t(*wave_hist)[256] = wave_hist_s;
+    const int64_t n = n_dev ? min((int64_t)*n_dev, n_cap) : n_cap;
+    const int ndig = 1 << bits;
+    const uint32_t mask = ndig - 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_ticket = atomicAdd(ticket, 1u);
+#pragma unroll
+    for (int w = 0; w < kBlock / kWave; ++w) wave_hist_s[w][tid] = 0;
+    __syncthreads();
+    const uint32_t tile = s_ticket;
+    if ((int64_t)tile * (kBlock * ITEMS) >= n) return;      // (deferred sizing) nothing here, and nothing after it either
+
+    const int64_t base = (int64_t)tile * (kBlock * ITEMS) + (int64_t)wave * (ITEMS * kWave);
+    uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int64_t idx = base + i * kWave + lane;
+        const bool valid = idx < n;
+        key[i] = valid ? keys_in[idx] : 0xFFFFFFFFu;
+        val[i] = valid ? vals_in[idx] : 0u;
+    }
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int64_t idx = base + i * kWave + lane;
+        const bool valid = idx < n;
+        const uint32_t d = (key[i] >> shift) & mask;
+        uint64_t peers = __ballot(valid);
+        for (int b = 0; b < bits; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const uint64_t m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        const uint32_t r = __popcll(peers & lt_mask);
+        const uint32_t cnt = __popcll(peers);
+        uint32_t pre = 0;
+        if (valid) pre = wave_hist[wave][d];
+        __builtin_amdgcn_wave_barrier();
+        if (valid && r == 0) wave_hist[wave][d] = pre + cnt;
+        __builtin_amdgcn_wave_barrier();
+        rank[i] = pre + r;
+    }
+    __syncthreads();
+    uint32_t run_len = 0;
+    if (tid < ndig) {
+#pragma unroll
+        for (int w = 0; w < kBlock / kWave; ++w) {
+            const uint32_t t = wave_hist_s[w][tid];
+            wave_hist_s[w][tid] = run_len;
+            run_len += t;
+        }
+        // publish this tile's count of digit `tid` (tile 0: it is already the inclusive count)
+        __hip_atomic_store(&status[(size_t)tile * 256 + tid], (tile == 0 ? kStatInc : kStatAgg) | run_len,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    uint32_t n_valid;
+    const uint32_t local_start = block_exclusive_scan(run_len, n_valid, scan_sums);
+    uint32_t dummy_total;
+    const uint32_t digit_base = block_exclusive_scan(tid < ndig ? ghist[tid] : 0u, dummy_total, scan_sums);
+    // decoupled look-back: keys with digit `tid` in the tiles before this one.  kLookBack status words are fetched at once
+    // (independent loads in flight together: a poll is a ~1 us round trip to the memory side, and with every tile of a
+    // P-sized sort resident at the same time a tile walks back over MANY counts before it meets an inclusive one).
+    uint32_t before = 0;
+    if (tid < ndig && tile > 0) {
+        int64_t pb = (int64_t)tile - 1;
+        int spins = 0;
+        bool done = false;
+        while (!done) {
+            uint32_t sw[kLookBack];
+#pragma unroll
+            for (int k = 0; k < kLookBack; ++k)
+                sw[k] = pb - k >= 0 ? __hip_atomic_load(&status[(size_t)(pb - k) * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                    : kStatInc;                       // "tile -1": inclusive count 0
+            int used = 0;
+#pragma unroll
+            for (int k = 0; k < kLookBack; ++k) {
+                if (done || used != k) continue;                      // stopped at an earlier word of this window
+                const uint32_t flag = sw[k] & ~kStatMask;
+                if (flag == 0u) continue;                             // not published yet: poll again from here
+                before += sw[k] & kStatMask;
+                used = k + 1;
+                done = flag == kStatInc;
+            }
+            pb -= used;
+            if (!done && used < kLookBack) {
+                if (++spins > kSpinLimit) { *err = 1u; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __hip_atomic_store(&status[(size_t)tile * 256 + tid], kStatInc | ((before + run_len) & kStatMask),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid < ndig) {
+        dig_start[tid] = local_start;
+        glob_base[tid] = digit_base + before - local_start;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int64_t idx = base + i * kWave + lane;
+        if (idx < n) {
+            const uint32_t d = (key[i] >> shift) & mask;
+            const uint32_t lp = dig_start[d] + wave_hist_s[wave][d] + rank[i];
+            stage_k[lp] = key[i];
+            stage_v[lp] = val[i];
+        }
+    }
+    __syncthreads();
+    for (uint32_t j = tid; j < n_valid; j += kBlock) {
+        const uint32_t k = stage_k[j];
+        const uint32_t pos = glob_base[(k >> shift) & mask] + j;
+        keys_out[pos] = k;
+        vals_out[pos] = stage_v[j];
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void tile_ranges_kernel(const uint32_t* __restrict__ tile_keys, int64_t D_cap,
                                                              const uint32_t* __restrict__ n_dev,
                                                              uint2* __restrict__ ranges) {
@@ -324,8 +500,97 @@ size_t scan_tmp_bytes(int64_t n) {
 
 size_t sort_tmp_bytes(int64_t n) {
     const int64_t hist = (int64_t)256 * sort_blocks_for(n > 0 ? n : 1);
-    // histogram table + 256 row totals; the tail is also what exclusive_scan_u32 callers borrow as scan scratch
-    return align_up((size_t)hist * sizeof(uint32_t)) + align_up(256 * sizeof(uint32_t)) + scan_tmp_bytes(hist);
+    // legacy pass: histogram table + 256 row totals; the tail is also what exclusive_scan_u32 callers borrow as scan scratch
+    const size_t legacy = align_up((size_t)hist * sizeof(uint32_t)) + align_up(256 * sizeof(uint32_t)) + scan_tmp_bytes(hist);
+    // one-launch passes: [header: 4 x 256 digit histograms | 4 tickets | error word][4 status tables of `hist` words]
+    const int64_t tiles4 = ((n > 0 ? n : 1) + kBlock * 4 - 1) / (kBlock * 4);            // the smaller tile size: upper bound
+    const size_t sweep = align_up(kSweepHeaderWords * sizeof(uint32_t)) + 4 * align_up((size_t)256 * tiles4 * sizeof(uint32_t));
+    return legacy > sweep ? legacy : sweep;
+}
+
+// keys per thread of a one-launch pass: the look-back chain grows with the number of tiles, so mid-size sorts take
+// 4096-key tiles earlier than the three-launch passes do (OGS_SWEEP_ITEMS=4|16 forces one for A-B runs)
+static int sweep_items_for(int64_t n) {
+    static const int forced = [] { const char* e = getenv("OGS_SWEEP_ITEMS"); return e ? atoi(e) : 0; }();
+    if (forced == 4 || forced == 16) return forced;
+    return n <= (int64_t)(256 << 10) ? 4 : 16;
+}
+
+// One launch per pass pays where the sort is LAUNCH-bound, i.e. small: back to back on the GPU the three-launch passes are
+// faster at every size (profiles/r03_radix_variants.json: 51 vs 58 us at 100 k keys, 90 vs 110 at 1 M, 266 vs 347 at 8 M --
+// the look-back chain and the ticket round trip cost more than two launch boundaries), but a 100 k-Gaussian step is paced
+// by the host's enqueue rate, and ten launches fewer per step took 19 % off its wall time (profiles/r03_c2_c3_host.json).
+// OGS_RADIX=legacy / sweep forces one variant everywhere (A-B runs, tests).
+bool radix_onesweep_enabled(int64_t n) {
+    static const int forced = [] {
+        const char* e = getenv("OGS_RADIX");
+        return !e ? 0 : strcmp(e, "legacy") == 0 ? 1 : strcmp(e, "sweep") == 0 ? 2 : 0;
+    }();
+    if (forced == 1 || n >= (int64_t)kStatMask) return false;          // counts travel in 30 bits of the status word
+    return forced == 2 || n <= (int64_t)(256 << 10);
+}
+
+namespace {
+struct SweepTmp {
+    uint32_t* ghist;      // [4][256]
+    uint32_t* ticket;     // [4]
+    uint32_t* err;        // [1]
+    uint32_t* status[4];  // [tiles][256] each
+    size_t zero_bytes;    // header + the status tables of the passes in use
+    static SweepTmp carve(void* tmp, int64_t n, int npass) {
+        SweepTmp t;
+        char* p = static_cast<char*>(tmp);
+        t.ghist = reinterpret_cast<uint32_t*>(p);
+        t.ticket = t.ghist + 4 * 256;
+        t.err = t.ticket + 4;
+        const int items = sweep_items_for(n);
+        const int64_t tiles = ((n > 0 ? n : 1) + (int64_t)kBlock * items - 1) / ((int64_t)kBlock * items);
+        const size_t table = align_up((size_t)256 * tiles * sizeof(uint32_t));
+        char* q = p + align_up(kSweepHeaderWords * sizeof(uint32_t));
+        for (int i = 0; i < 4; ++i) t.status[i] = reinterpret_cast<uint32_t*>(q + (size_t)i * table);
+        t.zero_bytes = align_up(kSweepHeaderWords * sizeof(uint32_t)) + (size_t)npass * table;
+        return t;
+    }
+};
+}  // namespace
+
+// Start of a sort of `npass` digit passes over the SAME multiset of keys: zero the scratch, histogram every digit.
+int radix_sort_begin(const uint32_t* keys, int64_t n, const uint32_t* n_dev, int npass, const int* shifts, const int* bits,
+                     void* tmp, hipStream_t stream, int debug) {
+    if (n <= 0) return OGS_OK;
+    if (npass < 1 || npass > 4) { set_error("radix_sort_begin: npass=%d out of range", npass); return OGS_ERR_INVALID_ARG; }
+    const SweepTmp t = SweepTmp::carve(tmp, n, npass);
+    OGS_HIP_CHECK(hipMemsetAsync(tmp, 0, t.zero_bytes, stream));
+    RadixPlanDev plan{};
+    plan.npass = npass;
+    for (int i = 0; i < npass; ++i) {
+        if (bits[i] < 1 || bits[i] > 8) { set_error("radix_sort_begin: bits=%d out of range", bits[i]); return OGS_ERR_INVALID_ARG; }
+        plan.shift[i] = shifts[i];
+        plan.bits[i] = bits[i];
+    }
+    const int64_t want = (n + kBlock * 16 - 1) / (kBlock * 16);
+    const int grid = (int)(want < 1 ? 1 : (want > kHistAllBlocks ? kHistAllBlocks : want));
+    OGS_LAUNCH(radix_hist_all_kernel, dim3(grid), dim3(kBlock), 0, stream, keys, n, n_dev, plan, t.ghist);
+    OGS_LAUNCH_CHECK(debug, stream);
+    return OGS_OK;
+}
+
+// Pass `pass` (0-based, as planned in radix_sort_begin) of the sort: ONE launch.
+int radix_sort_pass(int pass, int npass, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
+                    int64_t n, int shift, int bits, void* tmp, hipStream_t stream, int debug, const uint32_t* n_dev) {
+    if (n <= 0) return OGS_OK;
+    const SweepTmp t = SweepTmp::carve(tmp, n, npass);
+    const int items = sweep_items_for(n);
+    const int nb = (int)((n + (int64_t)kBlock * items - 1) / ((int64_t)kBlock * items));
+    if (items == 4) {
+        OGS_LAUNCH(radix_onesweep_kernel<4>, dim3(nb), dim3(kBlock), 0, stream, keys_in, vals_in, keys_out, vals_out, n, n_dev,
+                   shift, bits, (const uint32_t*)(t.ghist + pass * 256), t.status[pass], t.ticket + pass, t.err);
+    } else {
+        OGS_LAUNCH(radix_onesweep_kernel<16>, dim3(nb), dim3(kBlock), 0, stream, keys_in, vals_in, keys_out, vals_out, n, n_dev,
+                   shift, bits, (const uint32_t*)(t.ghist + pass * 256), t.status[pass], t.ticket + pass, t.err);
+    }
+    OGS_LAUNCH_CHECK(debug, stream);
+    return OGS_OK;
 }
 
 int exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int64_t n, uint32_t* total,

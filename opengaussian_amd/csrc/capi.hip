@@ -120,7 +120,7 @@ using namespace ogs;
 
 extern "C" {
 
-int ogs_version(void) { return 210; }
+int ogs_version(void) { return 300; }
 
 /* Per-kernel timing with HIP events recorded on the launch stream (bench.py's `roofline` leg).
  * ogs_prof_enable(1) starts a fresh recording; ogs_prof_collect() waits for the recorded events and
@@ -200,9 +200,16 @@ int ogs_raster_forward_geometry(const OgsRasterFwdArgs* a, void* stream_, int64_
         rc = launch_preprocess(*a, gs, gt, s);
         if (rc != OGS_OK) return rc;
         // depth sort of the P Gaussians: 4 x 8-bit stable passes, ends in keys[0]/order[0]
+        const bool sweep = radix_onesweep_enabled(a->P);
+        if (sweep) {
+            const int shifts[4] = {0, 8, 16, 24}, nbits[4] = {8, 8, 8, 8};
+            rc = radix_sort_begin(gt.keys[0], a->P, nullptr, 4, shifts, nbits, gt.sort_tmp, s, a->debug);
+            if (rc != OGS_OK) return rc;
+        }
         for (int pass = 0; pass < 4; ++pass) {
             const int in = pass & 1, out = in ^ 1;
-            rc = radix_pass(gt.keys[in], gt.order[in], gt.keys[out], gt.order[out], a->P, 8 * pass, 8, gt.sort_tmp, s, a->debug);
+            rc = sweep ? radix_sort_pass(pass, 4, gt.keys[in], gt.order[in], gt.keys[out], gt.order[out], a->P, 8 * pass, 8, gt.sort_tmp, s, a->debug)
+                       : radix_pass(gt.keys[in], gt.order[in], gt.keys[out], gt.order[out], a->P, 8 * pass, 8, gt.sort_tmp, s, a->debug);
             if (rc != OGS_OK) return rc;
         }
         // offsets[r] = exclusive scan of tiles_touched in depth order; total = num_rendered
@@ -254,11 +261,20 @@ static int render_impl(const OgsRasterFwdArgs* a, int64_t D, bool deferred, hipS
         const uint32_t* n_dev = deferred ? gt.num_rendered : nullptr;
         rc = launch_duplicate(*a, gs, gt, bt.tile_keys[0], vbuf[0], (uint32_t)D, s);
         if (rc != OGS_OK) return rc;
+        const bool sweep = radix_onesweep_enabled(D);
+        int shifts[4], nbits[4];
+        for (int p = 0; p < passes; ++p) {
+            shifts[p] = p * per;
+            nbits[p] = (p == passes - 1) ? (bits == 0 ? 1 : bits - shifts[p]) : per;
+        }
+        if (sweep) {
+            rc = radix_sort_begin(bt.tile_keys[0], D, n_dev, passes, shifts, nbits, bt.sort_tmp, s, a->debug);
+            if (rc != OGS_OK) return rc;
+        }
         for (int p = 0; p < passes; ++p) {
             const int in = p & 1, out = in ^ 1;
-            const int shift = p * per;
-            const int nb = (p == passes - 1) ? (bits == 0 ? 1 : bits - shift) : per;
-            rc = radix_pass(bt.tile_keys[in], vbuf[in], bt.tile_keys[out], vbuf[out], D, shift, nb, bt.sort_tmp, s, a->debug, n_dev);
+            rc = sweep ? radix_sort_pass(p, passes, bt.tile_keys[in], vbuf[in], bt.tile_keys[out], vbuf[out], D, shifts[p], nbits[p], bt.sort_tmp, s, a->debug, n_dev)
+                       : radix_pass(bt.tile_keys[in], vbuf[in], bt.tile_keys[out], vbuf[out], D, shifts[p], nbits[p], bt.sort_tmp, s, a->debug, n_dev);
             if (rc != OGS_OK) return rc;
         }
         rc = launch_tile_ranges(bt.tile_keys[passes & 1], D, is.ranges, tiles, s, a->debug, n_dev);
@@ -345,6 +361,37 @@ int ogs_selftest_wave_fold16(const float* in, float* out, void* stream_) {
 int ogs_selftest_tile_order(const uint32_t* ranges, int64_t vtiles, uint32_t* order, void* stream_) {
     if (!ranges || !order || vtiles <= 0) { set_error("selftest: NULL pointer / no tiles"); return OGS_ERR_INVALID_ARG; }
     return launch_tile_order_test(ranges, vtiles, order, static_cast<hipStream_t>(stream_));
+}
+
+size_t ogs_selftest_radix_tmp_bytes(int64_t n) { return sort_tmp_bytes(n > 0 ? n : 1); }
+
+int ogs_selftest_radix_sort(uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, uint32_t* vals1, int64_t n, int32_t key_bits,
+                            int32_t variant, void* tmp, int32_t* result_buffer, void* stream_) {
+    if (!result_buffer) { set_error("selftest_radix_sort: NULL result_buffer"); return OGS_ERR_INVALID_ARG; }
+    *result_buffer = 0;
+    if (n <= 0) return OGS_OK;
+    if (!keys0 || !vals0 || !keys1 || !vals1 || !tmp || key_bits < 1 || key_bits > 32) {
+        set_error("selftest_radix_sort: bad arguments"); return OGS_ERR_INVALID_ARG;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream_);
+    uint32_t* k[2] = {keys0, keys1};
+    uint32_t* v[2] = {vals0, vals1};
+    const int passes = (key_bits + 7) / 8, per = (key_bits + passes - 1) / passes;
+    int shifts[4], nbits[4];
+    for (int p = 0; p < passes; ++p) { shifts[p] = p * per; nbits[p] = p == passes - 1 ? key_bits - shifts[p] : per; }
+    int rc = OGS_OK;
+    if (variant == 1) {
+        rc = radix_sort_begin(k[0], n, nullptr, passes, shifts, nbits, tmp, s, 0);
+        if (rc != OGS_OK) return rc;
+    }
+    for (int p = 0; p < passes; ++p) {
+        const int in = p & 1, out = in ^ 1;
+        rc = variant == 1 ? radix_sort_pass(p, passes, k[in], v[in], k[out], v[out], n, shifts[p], nbits[p], tmp, s, 0)
+                          : radix_pass(k[in], v[in], k[out], v[out], n, shifts[p], nbits[p], tmp, s, 0);
+        if (rc != OGS_OK) return rc;
+    }
+    *result_buffer = passes & 1;
+    return OGS_OK;
 }
 
 int ogs_raster_export_binning(const OgsRasterFwdArgs* a, int64_t D, uint64_t* keys_out, uint32_t* ranges_out,

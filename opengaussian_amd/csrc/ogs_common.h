@@ -211,7 +211,16 @@ size_t sort_tmp_bytes(int64_t n);                      // histogram + scan scrat
 // written there (device).  `gather` (optional) makes element i = in[gather[i]].
 int exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int64_t n,
                        uint32_t* total, void* tmp, hipStream_t stream, int debug);
-// One stable LSD pass on bits [shift, shift+bits) of keys_in (bits <= 8).
+// One-launch-per-pass variant (decoupled look-back): radix_sort_begin zeroes the scratch and histograms every digit of
+// the `npass` planned passes in one read of the keys; radix_sort_pass is pass `pass` of that plan (ONE launch).
+// radix_onesweep_enabled(n): false for n >= 2^30 or OGS_RADIX=legacy (then use radix_pass, three launches per pass).
+bool radix_onesweep_enabled(int64_t n);
+int radix_sort_begin(const uint32_t* keys, int64_t n, const uint32_t* n_dev, int npass, const int* shifts, const int* bits,
+                     void* tmp, hipStream_t stream, int debug);
+int radix_sort_pass(int pass, int npass, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
+                    uint32_t* vals_out, int64_t n, int shift, int bits, void* tmp, hipStream_t stream, int debug,
+                    const uint32_t* n_dev = nullptr);
+// One stable LSD pass on bits [shift, shift+bits) of keys_in (bits <= 8): histogram table, row scan, scatter.
 int radix_pass(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
                int64_t n, int shift, int bits, void* tmp, hipStream_t stream, int debug,
                const uint32_t* n_dev = nullptr);

@@ -631,7 +631,7 @@ def test_random_configurations_backward_parity(gpu_device):
         mode = it % 3                                             # 0: SH colours, 1: 6-D features, 2: SH + cov3D input
         sc, cam = helpers.tiny_scene(P, W, H, f, seed=4000 + it, log_scale_mean=lsm, with_ties=bool(it % 4 == 0))
         if it % 4 == 1:
-            sc.opacities[:] = torch.rand_like(sc.opacities) ** 3
+            sc.opacities[:] = torch.rand(sc.opacities.shape, generator=torch.Generator().manual_seed(5000 + it)) ** 3
         if mode == 1:
             inp, bg = helpers.oracle_inputs(sc, cam, feat=sc.ins_feat), (0.0,) * 6
         else:
@@ -663,7 +663,7 @@ def test_random_configurations_forward_parity(gpu_device):
         bg = tuple(float(x) for x in rng.uniform(0, 1, 3))
         sc, cam = helpers.tiny_scene(P, W, H, f, seed=1000 + it, log_scale_mean=lsm, with_ties=bool(it % 3 == 0))
         if it % 4 == 1:
-            sc.opacities[:] = torch.rand_like(sc.opacities) ** 3          # many near-threshold opacities
+            sc.opacities[:] = torch.rand(sc.opacities.shape, generator=torch.Generator().manual_seed(6000 + it)) ** 3   # many near-threshold opacities
         inp = helpers.oracle_inputs(sc, cam, use_sh=use_sh, use_cov=use_cov)
         ref = ro.render_forward(W=W, H=H, tanfovx=W / (2 * f), tanfovy=H / (2 * f), bg=np.array(bg, np.float32),
                                 sh_degree=3, **inp)
