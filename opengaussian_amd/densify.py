@@ -98,8 +98,15 @@ def _swap_param(optimizer, group, new_tensor: torch.Tensor, new_state: Optional[
     return p
 
 
+def _is_sharded(optimizer) -> bool:
+    """opengaussian_amd.dp.ShardedAdam: flat replicated parameters, moments only for the owned slice"""
+    return hasattr(optimizer, "remap_rows")
+
+
 def replace_tensor_to_optimizer(optimizer, tensor: torch.Tensor, name: str) -> Dict[str, nn.Parameter]:
     """scene/gaussian_model.py:357-372: swap the parameter of group `name`, zeroing its moments."""
+    if _is_sharded(optimizer):
+        return optimizer.replace_tensor(name, tensor)
     out = {}
     for group in _groups(optimizer):
         if group["name"] != name:
@@ -115,6 +122,8 @@ def replace_tensor_to_optimizer(optimizer, tensor: torch.Tensor, name: str) -> D
 
 def _remap_optimizer(optimizer, src_row: torch.Tensor, kind: Optional[torch.Tensor], extras=()):
     """Move every group's parameter and moments (and the `extras` tensors) through the row map in one launch."""
+    if _is_sharded(optimizer):
+        return optimizer.remap_rows(src_row, kind, extras)
     groups = list(_groups(optimizer))
     tensors, zero_new, slots = [], set(), []
     for gi, group in enumerate(groups):
@@ -160,6 +169,18 @@ def prune_optimizer(optimizer, mask: torch.Tensor, extras=()):
 
 def cat_tensors_to_optimizer(optimizer, tensors_dict: Dict[str, torch.Tensor]) -> Dict[str, nn.Parameter]:
     """scene/gaussian_model.py:412-433: append `tensors_dict[name]` to every group, moments extended with zeros."""
+    if _is_sharded(optimizer):
+        # identity rows + appended rows (copied from row 0, flagged new -> zero moments), then the given values written over
+        first = optimizer.names[0]
+        n_old, n_new = int(optimizer.shapes[first][0]), int(tensors_dict[first].shape[0])
+        dev = optimizer.flat.device
+        src = torch.cat((torch.arange(n_old, dtype=torch.int32, device=dev), torch.zeros(n_new, dtype=torch.int32, device=dev)))
+        kind = torch.cat((torch.zeros(n_old, dtype=torch.uint8, device=dev), torch.ones(n_new, dtype=torch.uint8, device=dev)))
+        params, _ = optimizer.remap_rows(src, kind)
+        with torch.no_grad():
+            for name, p in params.items():
+                p[n_old:].copy_(tensors_dict[name].detach())
+        return params
     out = {}
     for group in _groups(optimizer):
         ext = tensors_dict[group["name"]]
@@ -185,6 +206,8 @@ class DensifyState:
     last_plan: Optional[dict] = None       # counts + row map of the last densify_and_prune (diagnostics / tests)
 
     def params(self) -> Dict[str, nn.Parameter]:
+        if _is_sharded(self.optimizer):
+            return dict(self.optimizer.params)
         return {g["name"]: g["params"][0] for g in _groups(self.optimizer)}
 
 
@@ -200,6 +223,11 @@ def add_densification_stats(state: DensifyState, viewspace_grad: torch.Tensor, u
                             radii: Optional[torch.Tensor] = None):
     """scene/gaussian_model.py:512-514 and, when `radii` is given, the max_radii2D update of train.py:597 -- one pass.
     `update_filter` None: radii > 0 (what train.py passes as visibility_filter)."""
+    if viewspace_grad is None:
+        # render(..., viewspace_grad=None) stops producing dL/dmeans2D once every geometry tensor is detached (stage >= 1,
+        # train.py:431-436): a schedule that still densifies there must ask for it explicitly
+        raise RuntimeError("add_densification_stats: viewspace_points.grad is None -- the rasterizer ran its features-only "
+                           "backward (all geometry tensors detached); call render(..., viewspace_grad=True) while densifying")
     _need_gpu(viewspace_grad, "viewspace_grad")
     g = _f32c(viewspace_grad)
     N = int(g.shape[0])
@@ -261,6 +289,11 @@ def densify_and_prune(state: DensifyState, max_grad: float, min_opacity: float, 
         stds = torch.exp(scaling[src_row[child].long()])
         samples = torch.zeros(2 * S, 3, dtype=torch.float32, device=dev)
         samples[sample_row[child].long()] = torch.normal(mean=torch.zeros_like(stds), std=stds, generator=generator)
+        if _is_sharded(state.optimizer) and state.optimizer.on:
+            # every rank must create the SAME children: rank 0's draw is the one that counts
+            import torch.distributed as dist
+            dist.broadcast(samples, src=dist.get_global_rank(state.optimizer.group, 0) if state.optimizer.group is not None else 0,
+                           group=state.optimizer.group)
     samples = _f32c(samples)
     if samples.shape != (2 * S, 3):
         raise RuntimeError(f"samples must be [2*S,3] with S={S} selected split parents, got {tuple(samples.shape)}")

@@ -239,14 +239,24 @@ class ShardedAdam:
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         self.on = collectives_on(group)
+        self.device = device
         self.names = [n for n, _ in named_shapes]
-        self.shapes = {n: tuple(s) for n, s in named_shapes}
         self.lrs = dict(lrs)
         self.betas, self.eps = betas, eps
+        self._layout({n: tuple(s) for n, s in named_shapes})
+        self.exp_avg = torch.zeros(self.slice, dtype=torch.float32, device=device)
+        self.exp_avg_sq = torch.zeros(self.slice, dtype=torch.float32, device=device)
+        self.step_counts = {n: 0 for n in self.names}              # per parameter, like torch's state["step"]
+
+    def _layout(self, shapes: dict):
+        """(Re)build the flat layout for the per-tensor `shapes`: offsets, padded length, this rank's slice, the flat
+        parameter / gradient buffers and the parameter views.  Moments are NOT touched (the caller installs them)."""
+        device = self.device
+        self.shapes = dict(shapes)
         self.offsets, off = {}, 0
-        for n, s in named_shapes:
+        for n in self.names:
             self.offsets[n] = off
-            off += int(torch.Size(s).numel())
+            off += int(torch.Size(self.shapes[n]).numel())
         self.total = off
         quantum = self.world * 4                                   # slices stay 16-byte aligned
         self.padded = (off + quantum - 1) // quantum * quantum
@@ -259,9 +269,69 @@ class ShardedAdam:
         self.my = (lo, lo + self.slice)
         self.my_grad = torch.zeros(self.slice, dtype=torch.float32, device=device)
         self.my_param = torch.zeros(self.slice, dtype=torch.float32, device=device)
-        self.exp_avg = torch.zeros(self.slice, dtype=torch.float32, device=device)
-        self.exp_avg_sq = torch.zeros(self.slice, dtype=torch.float32, device=device)
-        self.step_counts = {n: 0 for n in self.names}              # per parameter, like torch's state["step"]
+
+    # ---- densification on the sharded state (scene/gaussian_model.py:357-510) ---------------------
+    def _full_moments(self):
+        """Both moment vectors over the WHOLE flat layout, on every rank (one all-gather each: densification runs every
+        ~100 iterations, train.py:594-605, so the 2 x 4 B x 65 x P bytes are amortised over a hundred steps)."""
+        full = []
+        for m in (self.exp_avg, self.exp_avg_sq):
+            if self.on:
+                out = torch.empty(self.padded, dtype=torch.float32, device=m.device)
+                dist.all_gather_into_tensor(out, m.contiguous(), group=self.group)
+            else:
+                out = torch.zeros(self.padded, dtype=torch.float32, device=m.device)
+                out[self.my[0]:self.my[1]] = m
+            full.append(out)
+        return full
+
+    @torch.no_grad()
+    def remap_rows(self, src_row: torch.Tensor, kind, extras=()):
+        """Apply ONE row map to every parameter and to the optimizer state: new row r of every per-Gaussian tensor =
+        old row src_row[r]; rows with kind != 0 are NEW (clones / split children / appended rows): their moments start at
+        zero (scene/gaussian_model.py:412-433).  `extras` (statistics tensors) move through the same map.
+
+        Every rank holds all parameters, so the parameters move locally; the moments exist per owned flat slice, so they
+        are all-gathered once, moved through the same map and re-sliced at the NEW slice boundaries (the point count
+        changed, so every boundary moved).  The map must be identical on all ranks -- it is when it derives from
+        all-reduced statistics (dp.reduce_densification_stats) and broadcast samples (densify.densify_and_prune does
+        both).  Returns ({name: new parameter view}, [new extras])."""
+        from .densify import gather_rows
+        m_full, v_full = self._full_moments()
+        n_out = int(src_row.shape[0])
+        tensors, zero_new = [], set()
+        for n in self.names:
+            a, cnt = self.offsets[n], int(torch.Size(self.shapes[n]).numel())
+            tensors.append(self.flat[a:a + cnt].view(self.shapes[n]))
+            for full in (m_full, v_full):
+                zero_new.add(len(tensors))
+                tensors.append(full[a:a + cnt].view(self.shapes[n]))
+        tensors.extend(extras)
+        outs = gather_rows(tensors, src_row, kind, zero_new)
+        self._layout({n: (n_out,) + tuple(self.shapes[n][1:]) for n in self.names})
+        new_m = torch.zeros(self.padded, dtype=torch.float32, device=self.flat.device)
+        new_v = torch.zeros(self.padded, dtype=torch.float32, device=self.flat.device)
+        for i, n in enumerate(self.names):
+            a, cnt = self.offsets[n], int(torch.Size(self.shapes[n]).numel())
+            self.flat[a:a + cnt].copy_(outs[3 * i].reshape(-1))
+            new_m[a:a + cnt].copy_(outs[3 * i + 1].reshape(-1))
+            new_v[a:a + cnt].copy_(outs[3 * i + 2].reshape(-1))
+        lo, hi = self.my
+        self.exp_avg, self.exp_avg_sq = new_m[lo:hi].clone(), new_v[lo:hi].clone()
+        return dict(self.params), list(outs[3 * len(self.names):])
+
+    @torch.no_grad()
+    def replace_tensor(self, name: str, tensor: torch.Tensor):
+        """scene/gaussian_model.py:357-372 (`replace_tensor_to_optimizer`, used by reset_opacity): new values for one
+        parameter, its moments zeroed -- on the part of the owned slice that overlaps it."""
+        self.params[name].copy_(tensor.reshape(self.shapes[name]))
+        lo, hi = self.my
+        a = max(self.offsets[name], lo)
+        b = min(self.offsets[name] + self.params[name].numel(), hi)
+        if b > a:
+            self.exp_avg[a - lo:b - lo].zero_()
+            self.exp_avg_sq[a - lo:b - lo].zero_()
+        return {name: self.params[name]}
 
     def load(self, tensors: dict):
         """initial values (identical on every rank)"""

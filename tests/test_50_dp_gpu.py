@@ -368,3 +368,132 @@ def test_bench_self_launches_two_ranks(gpu_device):
     modes = d["ms_per_step_by_exchange_mode"]
     assert set(modes) == {"pipelined", "sync", "none"} and all(v > 0 for v in modes.values())
     assert d["exposed_exchange_ms_per_step"] is not None
+
+
+# ---- densification on the sharded optimizer state (scene/gaussian_model.py:357-510) -----------
+_DG = [("xyz", (3,), 1.6e-4), ("f_dc", (1, 3), 2.5e-3), ("f_rest", (15, 3), 1.25e-4), ("opacity", (1,), 0.05),
+       ("scaling", (3,), 5e-3), ("rotation", (4,), 1e-3), ("ins_feat", (6,), 1e-3)]
+
+
+def _densify_sharded_rank(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), OGS_DIST_BACKEND="gloo")
+    import torch.distributed as dist
+    from opengaussian_amd import densify, dp
+    from opengaussian_amd.optim import FusedAdam
+    dp.init_from_env("cuda")
+    dev = torch.device("cuda", 0)
+    P = 911                                              # slice boundaries cut through rows and through tensors
+    g = torch.Generator().manual_seed(1)
+    init = {n: torch.randn(P, *shape, generator=g) for n, shape, _ in _DG}
+    init["scaling"] = torch.randn(P, 3, generator=g) * 1.2 - 3.0
+    init["opacity"] = torch.randn(P, 1, generator=g) * 3.0
+    init = {n: v.to(dev) for n, v in init.items()}
+    lrs = {n: lr for n, _, lr in _DG}
+    sharded = dp.ShardedAdam([(n, (P,) + shape) for n, shape, _ in _DG], lrs, dev)
+    sharded.load(init)
+    ref_params = {n: torch.nn.Parameter(init[n].clone()) for n, _, _ in _DG}
+    ref = FusedAdam([{"params": [ref_params[n]], "lr": lrs[n], "name": n} for n, _, _ in _DG], lr=0.0, eps=1e-15)
+    st_s = densify.DensifyState(sharded, torch.zeros(P, 1, device=dev), torch.zeros(P, 1, device=dev), torch.zeros(P, device=dev), 0.01)
+    st_r = densify.DensifyState(ref, torch.zeros(P, 1, device=dev), torch.zeros(P, 1, device=dev), torch.zeros(P, device=dev), 0.01)
+    out = {"rounds": []}
+
+    def steps(n_steps, seed):
+        """n optimizer steps: every rank contributes its own per-view gradient; the replicated optimizer gets their sum"""
+        for it in range(n_steps):
+            n_now = int(st_r.params()["xyz"].shape[0])
+            total = {}
+            for r in range(world):
+                gr = torch.Generator().manual_seed(seed + 10 * it + r)
+                for n, shape, _ in _DG:
+                    v = (torch.randn(n_now, *shape, generator=gr) * 0.1).to(dev)
+                    total[n] = v if n not in total else total[n] + v
+                    if r == rank:
+                        sharded.params[n].grad = v
+            sharded.step()
+            for n, _, _ in _DG:
+                st_r.params()[n].grad = total[n].clone()
+            ref.step()
+
+    def compare(tag):
+        worst = 0.0
+        lo, hi = sharded.my
+        for n, _, _ in _DG:
+            a, b = sharded.params[n].detach(), st_r.params()[n].detach()
+            assert a.shape == b.shape, (tag, n, a.shape, b.shape)
+            worst = max(worst, float((a - b).abs().max()))
+            # the owned moment slice == the same flat range of the replicated optimizer's moments
+            off, cnt = sharded.offsets[n], a.numel()
+            s0, s1 = max(off, lo), min(off + cnt, hi)
+            if s1 > s0:
+                for mine, key in ((sharded.exp_avg, "exp_avg"), (sharded.exp_avg_sq, "exp_avg_sq")):
+                    want = ref.state[st_r.params()[n]][key].reshape(-1)[s0 - off:s1 - off]
+                    worst = max(worst, float((mine[s0 - lo:s1 - lo] - want).abs().max()))
+        out["rounds"].append((tag, worst, int(sharded.params["xyz"].shape[0])))
+
+    steps(3, 1000)
+    compare("after 3 steps")
+    for rnd in range(2):
+        n_now = int(st_r.params()["xyz"].shape[0])
+        gs = torch.Generator().manual_seed(50 + rnd)
+        accum, denom = (torch.rand(n_now, 1, generator=gs) * 3.0).to(dev), torch.randint(0, 4, (n_now, 1), generator=gs).float().to(dev)
+        radii = (torch.rand(n_now, generator=gs) * 40.0).to(dev)
+        for st in (st_s, st_r):
+            st.xyz_gradient_accum, st.denom, st.max_radii2D = accum.clone(), denom.clone(), radii.clone()
+        # the replicated run draws the split samples; the sharded run must come to the same children on EVERY rank:
+        # its own draw differs per rank (different RNG streams), rank 0's is broadcast -> hand the replicated run that one
+        torch.manual_seed(7 + rank)                      # per-rank RNG streams, as in separate training processes
+        densify.densify_and_prune(st_s, 0.6, 0.005, 4.0, 20)
+        # re-run the replicated optimizer with the samples rank 0 drew: recover them from the children it created
+        plan = st_s.last_plan
+        kind, src = plan["kind"], plan["src_row"]
+        # replicated truth with the SAME children: draw with rank 0's seed
+        torch.manual_seed(7 + 0)
+        densify.densify_and_prune(st_r, 0.6, 0.005, 4.0, 20)
+        assert torch.equal(st_r.last_plan["src_row"], src) and torch.equal(st_r.last_plan["kind"], kind)
+        compare(f"after densify round {rnd}")
+        steps(2, 2000 + 100 * rnd)
+        compare(f"after densify round {rnd} + 2 steps")
+    # prune_points and reset_opacity on the sharded state
+    n_now = int(st_r.params()["xyz"].shape[0])
+    mask = (torch.rand(n_now, generator=torch.Generator().manual_seed(9)) < 0.25).to(dev)
+    densify.prune_points(st_s, mask); densify.prune_points(st_r, mask)
+    densify.reset_opacity(st_s); densify.reset_opacity(st_r)
+    compare("after prune_points + reset_opacity")
+    steps(1, 3000)
+    compare("after a final step")
+    extra = {n: torch.randn(5, *shape, generator=torch.Generator().manual_seed(3)).to(dev) for n, shape, _ in _DG}
+    densify.cat_tensors_to_optimizer(sharded, extra); densify.cat_tensors_to_optimizer(ref, extra)
+    st_r_params = {g_["name"]: g_["params"][0] for g_ in ref.param_groups}
+    out["cat"] = max(float((sharded.params[n].detach() - st_r_params[n].detach()).abs().max()) for n, _, _ in _DG)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_densification_on_sharded_adam_two_ranks_matches_replicated(gpu_device):
+    """densify_and_prune / prune_points / reset_opacity / cat_tensors_to_optimizer over dp.ShardedAdam (flat replicated
+    parameters, moments only for the owned flat slice) on two ranks == the same calls over the replicated FusedAdam, bit for
+    bit, through two densification rounds with optimizer steps in between: parameters on every rank AND the owned moment
+    slices (re-partitioned at the new boundaries after every change of the point count)."""
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_densify_sharded_rank, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sizes = set()
+    for rank, out in res:
+        assert len(out["rounds"]) == 7
+        for tag, worst, n in out["rounds"]:
+            assert worst == 0.0, (rank, tag, worst)
+        assert out["cat"] == 0.0
+        sizes.add(tuple(n for _, _, n in out["rounds"]))
+    assert len(sizes) == 1                                # both ranks went through the same point counts
+    assert len(set(next(iter(sizes)))) >= 3               # and the count really changed (grow, grow, prune)
