@@ -41,8 +41,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~6300 achievable
-# VALU issue peak: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles per SIMD, 2.4 GHz
-VALU_PEAK_GINST = 256 * 4 * 2.4 / 4
+# VALU issue peak, MEASURED on this part (scripts/ubench/valu_issue2.hip -> profiles/r03_valu_issue_price_list.json):
+# a SIMD issues one wave64 vector instruction per 2 cycles when >= 4 waves are resident AND every operand is a VGPR /
+# inline constant / literal (v_fma, v_mul, v_add, v_sub, v_mov, v_add_u32, v_and); per 4 cycles for ANY form with an SGPR
+# operand, DPP, v_cmp*, v_cndmask (SGPR-pair mask), v_max / v_min, shifts, v_cvt, v_pk_*, f64, v_readlane / v_writelane;
+# per 8 for v_exp / v_rcp.  `peak` below is the 2-cycle rate; `roofline_valu.issue_model` prices the dominant kernel's
+# own static instruction mix (scripts/isa_issue_mix.py -> profiles/r03_issue_mix.json).
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2
+MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16 (guide); k-means scores + one-hot accumulate run there
 
 
 def parse():
@@ -176,8 +182,32 @@ def kmeans_bench(device):
     torch.cuda.synchronize()
     dt = (time.time() - t0) / reps
     bytes_iter = N * (4 * d + 8) + 8 * k * d
-    return {"it_per_s": iters / dt, "ms_per_call": dt * 1e3, "N": N, "d": d, "k": k, "iters_per_call": iters,
-            "algorithmic_GBps": bytes_iter * iters / dt / 1e9}
+    out = {"it_per_s": iters / dt, "ms_per_call": dt * 1e3, "N": N, "d": d, "k": k, "iters_per_call": iters,
+           "algorithmic_GBps": bytes_iter * iters / dt / 1e9}
+    # per-kernel times (HIP events around every launch, separate run) and the two rooflines of the dominant pass
+    from opengaussian_amd import _lib
+    _lib.prof_filter("kmeans_")
+    _lib.prof_enable(1)
+    for _ in range(5):
+        lloyd(feat, cent.clone(), iters=iters, nchunks=N // 10000 + 1)
+    torch.cuda.synchronize()
+    prof = _lib.prof_collect()
+    _lib.prof_enable(0)
+    _lib.prof_filter("blend_")
+    kern = {kname: v["total_ms"] / v["calls"] * 1e3 for kname, v in prof.items()}
+    out["kernels_us_per_launch"] = kern
+    acc = next((v for kname, v in kern.items() if "accum" in kname), None)
+    if acc:
+        # accumulate pass: reads N*4*d bytes; matrix work = scores (2 * 64 K-slots per point and centre) + one-hot accumulate
+        # (3 bf16 terms x 2 * 16 columns per point and centre)
+        flops = N * k * (2 * 64 + 3 * 2 * 16)
+        out["roofline"] = {"kernel": "kmeans accumulate pass (scores + one-hot accumulate on the bf16 matrix path)",
+                           "bound": "hbm", "achieved": N * 4 * d / (acc * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                           "frac": N * 4 * d / (acc * 1e-6) / 1e9 / HBM_PEAK_GBPS, "avg_launch_us": acc,
+                           "matrix_pipe": {"achieved_TFLOPs": flops / (acc * 1e-6) / 1e12, "peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS,
+                                           "frac": flops / (acc * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS},
+                           "limiter": "vector issue of the operand packing / argmax around the MFMAs (DESIGN.md section 4)"}
+    return out
 
 
 def kmeans_cpu_baseline():
@@ -605,7 +635,20 @@ def main():
                     rate = n_valu / (per_kernel[dom]["avg_ms"] * 1e-3) / 1e9
                     valu = {"bound": "valu", "kernel": dom, "achieved": rate, "peak": VALU_PEAK_GINST, "unit": "G wave-instr/s",
                             "frac": rate / VALU_PEAK_GINST, "valu_wave_instructions_per_launch": n_valu,
+                            "peak_note": "2 cycles per wave64 instruction per SIMD (all-VGPR forms, measured); forms with an SGPR "
+                                         "operand, DPP, compares / selects, min / max issue at 4",
                             "source": sq.get("_source")}
+                    mix_file = os.path.join(ROOT, "profiles", "r03_issue_mix.json")
+                    if os.path.exists(mix_file):
+                        mix = json.load(open(mix_file)).get(dom.split("<")[0])
+                        if mix:
+                            cyc = float(mix["modelled_issue_cycles_per_valu"])
+                            mix_peak = 256 * 4 * 2.4 / cyc
+                            valu["issue_model"] = {"modelled_cycles_per_valu_instruction": cyc,
+                                                   "share_of_half_rate_or_slower_forms": mix["share_half_rate_or_slower"],
+                                                   "peak_for_this_mix": mix_peak, "frac_of_mix_peak": rate / mix_peak,
+                                                   "source": "scripts/isa_issue_mix.py (static mix of the kernel's vector "
+                                                             "instructions x the measured price list)"}
             except Exception:
                 valu = None
         roofline = None

@@ -51,14 +51,13 @@ struct WaveFoldLds {
     float w[kFoldRows * kFoldStride];
 };
 
-// no-return atomic add at (wave-uniform 64-bit base in SGPRs) + (32-bit per-lane byte offset): the SGPR-base addressing
-// form of global_atomic_add, which hipcc does not select by itself for atomics (it materialises a 64-bit VGPR address
-// per lane: two moves and a v_lshl_add_u64 per entry in the hot loop)
-__device__ __forceinline__ void atomic_add_sbase(double* base_uniform, uint32_t byte_off, double v) {
-    asm volatile("global_atomic_add_f64 %0, %1, %2" : : "v"(byte_off), "v"(v), "s"(base_uniform) : "memory");
+template <int N>
+__device__ __forceinline__ float row_bcast(float v) {     // lane n of every row of 16 lanes -> the whole row
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x150 + N, 0xF, 0xF, false));
 }
-__device__ __forceinline__ void atomic_add_sbase(float* base_uniform, uint32_t byte_off, float v) {
-    asm volatile("global_atomic_add_f32 %0, %1, %2" : : "v"(byte_off), "v"(v), "s"(base_uniform) : "memory");
+template <int N>
+__device__ __forceinline__ uint32_t row_bcast_u(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x150 + N, 0xF, 0xF, false);
 }
 
 // WIDE: all sixteen LDS reads in flight and four independent MFMA chains (the features-only kernel has the
@@ -113,7 +112,8 @@ struct RankOneFold {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int e = 4 * kq + r;
-            const uint32_t g = (uint32_t)__builtin_amdgcn_ds_bpermute(e * 4, (int)gidv);
+            // entry e sits in lane r of row kq of the stash register (push): DPP row broadcast instead of ds_bpermute
+            const uint32_t g = r == 0 ? row_bcast_u<0>(gidv) : r == 1 ? row_bcast_u<1>(gidv) : r == 2 ? row_bcast_u<2>(gidv) : row_bcast_u<3>(gidv);
             // 32-bit element offset from the (uniform) record array: SGPR-base addressing
             const uint32_t off = g * (uint32_t)GS + (uint32_t)(SLOT0 + m);
             if (e < cnt && m < NCH && !skip_atomics) atomicAdd(grad_rec + off, (ACC)d[r]);
@@ -131,9 +131,10 @@ struct RankOneFold {
             "s_mov_b32 m0, %3\n\t"
             "s_nop 0\n\t"
             "v_writelane_b32 %0, %2, m0\n\t"
+            "s_nop 1\n\t"                       // the flush reads the stash through DPP: two wait states after a VALU write
             "s_mov_b32 m0, %1"
             : "+v"(gidv), "=&s"(m0_saved)
-            : "s"(g), "s"(cnt));
+            : "s"(g), "s"(((cnt >> 2) << 4) | (cnt & 3)));                         // lane (entry & 3) of row (entry >> 2)
         ++cnt;
         if (cnt == kFoldRows) flush(grad_rec, lane);
     }
@@ -163,10 +164,6 @@ struct PairFoldLds {
     float t[16 * kPairStride];
 };
 
-template <int N>
-__device__ __forceinline__ float row_bcast(float v) {     // lane n of every row of 16 lanes -> the whole row
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x150 + N, 0xF, 0xF, false));
-}
 
 template <int C, bool DEPTH, int GS, typename ACC>
 struct PairFold {
@@ -223,9 +220,11 @@ struct PairFold {
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
             const int e = 2 * kq + rr;
-            const uint32_t g = (uint32_t)__builtin_amdgcn_ds_bpermute(e * 4, (int)gidv);
-            const float a = __int_as_float(__builtin_amdgcn_ds_bpermute(e * 4, __float_as_int(mxv))) - x0;
-            const float b = __int_as_float(__builtin_amdgcn_ds_bpermute(e * 4, __float_as_int(myv))) - y0;
+            // entry e = 2 kq + rr sits in lane rr of row kq of the stash registers (push): a DPP row broadcast (4 issue
+            // cycles) instead of a ds_bpermute (24) for each of the three values
+            const uint32_t g = rr == 0 ? row_bcast_u<0>(gidv) : row_bcast_u<1>(gidv);
+            const float a = (rr == 0 ? row_bcast<0>(mxv) : row_bcast<1>(mxv)) - x0;
+            const float b = (rr == 0 ? row_bcast<0>(myv) : row_bcast<1>(myv)) - y0;
             const float own = d[2 + rr];
             const float M0 = row_bcast<kSlotMoments>(own), Mu = row_bcast<kSlotMoments + 1>(own),
                         Mv = row_bcast<kSlotMoments + 2>(own);
@@ -258,9 +257,10 @@ struct PairFold {
             "v_writelane_b32 %0, %4, m0\n\t"
             "v_writelane_b32 %1, %5, m0\n\t"
             "v_writelane_b32 %2, %6, m0\n\t"
+            "s_nop 1\n\t"                       // the flush reads the stash through DPP: two wait states after a VALU write
             "s_mov_b32 m0, %3"
             : "+v"(gidv), "+v"(mxv), "+v"(myv), "=&s"(m0_saved)
-            : "s"(g), "s"(mx), "s"(my), "s"(cnt));
+            : "s"(g), "s"(mx), "s"(my), "s"(((cnt >> 1) << 4) | (cnt & 1)));        // lane (entry & 1) of row (entry >> 1)
         ++cnt;
         if (cnt == 8) flush(grad_rec, lane);
     }

@@ -216,23 +216,32 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
         const float power = blend_power(cur[2], cur[3], cur[4], dx, dy);
         const bool cand = fabsf(power + cur[5]) <= cur[5];
         if (__ballot(cand) != 0ull) {
-            bool stop = false;
+            bool any_stop = false;
             if (cand) {
                 float alpha = fminf(0.99f, cur[6] * __expf(power));
                 alpha = alpha >= kAlphaMin ? alpha : 0.f;
                 const float test_T = T * (1.0f - alpha);
-                stop = test_T < 0.0001f;                       // this entry is NOT applied (A.3)
-                const float w = stop ? 0.f : alpha * T;
+                const bool stop = test_T < 0.0001f;            // this entry is NOT applied (A.3)
+                float w = alpha * T;
+                // A pixel saturates once in its life, so most entries stop no lane of the wave: then no select is needed at
+                // all (three v_cndmask with an SGPR-pair mask = 12 issue cycles of the ~120 an entry costs; same arithmetic
+                // on both paths: the images are bit for bit the old ones)
+                if (__ballot(stop) == 0ull) {
+                    T = test_T;
+                } else {
+                    w = stop ? 0.f : w;
+                    T = stop ? T : test_T;
+                    fxe = stop ? kFar : fxe;
+                    any_stop = true;
+                }
                 const v2f w2 = {w, w};
 #pragma unroll
                 for (int k = 0; k < NPF; ++k)       // explicit FMA (the tiny pass reproduces these bits)
                     accp[k] = __builtin_elementwise_fma((v2f){rec_j.feat(2 * k), rec_j.feat(2 * k + 1)}, w2, accp[k]);
                 wacc += w;
-                T = stop ? T : test_T;
                 last = w > 0.f ? (uint32_t)j + 1u : last;
-                fxe = stop ? kFar : fxe;
             }
-            if (__ballot(stop) != 0ull) all_done = __ballot(fxe < kFarTest) == 0ull;   // whole wave finished?
+            if (__builtin_amdgcn_readfirstlane(__ballot(any_stop) != 0ull)) all_done = __ballot(fxe < kFarTest) == 0ull;   // whole wave finished?
         }
     };
     // Software pipeline over the wave-uniform index stream, in BATCHES of two records.  SMEM returns out of order,

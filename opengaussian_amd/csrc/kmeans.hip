@@ -22,7 +22,7 @@ namespace ogs {
 namespace {
 
 constexpr int kMaxD = OGS_KMEANS_MAX_DIM;
-constexpr int kMaxBlocks = 2048;     // 8 workgroups per CU keep the distance loop's LDS/VALU latency covered
+constexpr int kMaxBlocks = 1024;     // 4 workgroups per CU (what the GEMM pass keeps resident): 12.1 k it/s vs 11.5 k at 2048, fewer partial tables
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 // argmin over the first k_active centres of sum_j (x_j - c_j)^2, sequential fp32 accumulation in the order of
@@ -441,6 +441,260 @@ __global__ __launch_bounds__(kBlock) void kmeans_accum_bf16_kernel(const float* 
     }
 }
 
+// ---- distances as a GEMM on the bf16 matrix path (round 3) ----------------------------------------------------------
+// The reference computes its distances as a matrix product (torch.cdist goes through mm for more than 25 rows,
+// scene/kmeans_quantize.py:53-54).  So does this pass: argmin_c |x - c|^2 = argmax_c ( x.c - |c|^2 / 2 ), the scores of 16
+// points against 16 centres are ONE accumulator tile of v_mfma_f32_16x16x32_bf16, and fp32 accuracy comes from splitting
+// every fp32 operand into three bf16 terms hi + mid + lo that carry its 24 significant bits exactly (truncation split:
+// hi = top 16 bits, mid = top 16 bits of x - hi, lo = x - hi - mid): of the nine cross products the six with weight
+// >= 2^-16 are kept (hh, hm, hl, mh, mm, lh; the dropped ones are <= 2^-23 relative), every bf16 x bf16 product is exact
+// in fp32 and the sum runs in the MFMA's fp32 accumulator.  K layout (64 slots = two MFMAs; lane group g = lane >> 4
+// owns k = 8g .. 8g+7 of each): group g carries the six products of dimensions 2g and 2g+1 (12 slots) + 3 extra
+// slots: g = 0 / 1 the products of dimension 8, g = 2 the bias -|c|^2/2 (split like everything else, point side = 1).
+// Both operands are shifted by the mean of the active centres first: distances do not change, the magnitudes that
+// drive the cancellation in x.c - |c|^2/2 shrink from "distance to the origin" to "spread of the data".
+// Issue-rate background (profiles/r03_valu_issue_price_list.json): the direct-difference loop costs 9 SGPR-operand
+// subtractions (4 cycles each) + 9 FMAs (2) + compare/selects per point-wave and centre = ~66 cycles, 4224 per 64 x 64
+// block; this form: 32 MFMAs (16 cycles each) + ~1100 cycles of operand packing and argmax.
+// First-minimum tie rule: per lane the candidates are scanned in index order with a strict compare, lanes are merged
+// on (score, lower index).  Error of a score: ~1e-6 |x'| |c'| (fp32 accumulation over 64 terms) -- ids agree with the
+// float64 argmin except on near-ties of that size (the reference's own mm-based cdist has the same kind of error).
+typedef short bf16x8s __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pack_hi16(float lo_elem, float hi_elem) {      // {bf16(lo_elem), bf16(hi_elem)} by truncation
+    return __builtin_amdgcn_perm(__float_as_uint(hi_elem), __float_as_uint(lo_elem), 0x07060302u);
+}
+struct Split3 { float h, m, l; };
+__device__ __forceinline__ Split3 split3(float x) {
+    Split3 r;
+    r.h = __uint_as_float(__float_as_uint(x) & 0xFFFF0000u);
+    const float r1 = x - r.h;                                   // exact
+    r.m = __uint_as_float(__float_as_uint(r1) & 0xFFFF0000u);
+    r.l = r1 - r.m;                                             // exact, <= 8 significant bits: its top 16 bits hold all of it
+    return r;
+}
+// the 16 K-slots of a lane group, as two 8 x bf16 fragments: a = dimension 2g, b = dimension 2g+1, e = the three extras.
+// POINT side value per slot: [ah ah ah am am al | bh bh] [bh bm bm bl | e0 e1 e2 0]
+// CENTRE side value per slot: [ah am al ah am ah | bh bm] [bl bh bm bh | e0 e1 e2 0]
+__device__ __forceinline__ void frag_point(const Split3& a, const Split3& b, float e0, float e1, float e2, u32x4& f0, u32x4& f1) {
+    f0 = u32x4{pack_hi16(a.h, a.h), pack_hi16(a.h, a.m), pack_hi16(a.m, a.l), pack_hi16(b.h, b.h)};
+    f1 = u32x4{pack_hi16(b.h, b.m), pack_hi16(b.m, b.l), pack_hi16(e0, e1), pack_hi16(e2, 0.f)};
+}
+__device__ __forceinline__ void frag_centre(const Split3& a, const Split3& b, float e0, float e1, float e2, u32x4& f0, u32x4& f1) {
+    f0 = u32x4{pack_hi16(a.h, a.m), pack_hi16(a.l, a.h), pack_hi16(a.m, a.h), pack_hi16(b.h, b.m)};
+    f1 = u32x4{pack_hi16(b.l, b.h), pack_hi16(b.m, b.h), pack_hi16(e0, e1), pack_hi16(e2, 0.f)};
+}
+
+template <int CB, bool ACCUM, int DT>
+__global__ __launch_bounds__(kBlock) void kmeans_gemm_pass_kernel(const float* __restrict__ feat, int64_t N,
+                                                                  const float* __restrict__ centers, int k, int k_active,
+                                                                  int64_t* __restrict__ ids_out, int64_t id_offset,
+                                                                  float* __restrict__ partials) {
+    static_assert(DT == 6 || DT == 9, "the K layout covers the reference's two codebook widths");
+    constexpr int d = DT;
+    extern __shared__ float smem[];
+    float* rows = smem;                                            // [256 * d] staged rows
+    int* ids_s = reinterpret_cast<int*>(rows + kBlock * d);        // [256] ids of the staged rows (-1: no row)
+    float* wtab = rows;                                            // epilogue only (ACCUM): per-wave tables reuse `rows`
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, j = lane & 15;
+    const int da = 2 * g, db = 2 * g + 1;                          // this lane group's two dimensions (>= d: unused, zero)
+    const bool has8 = d == 9 && g < 2;
+    // shifted centres c' = c - mean(active centres) and their -|c'|^2 / 2, once per workgroup, through LDS (the rows region
+    // is free until the first trip): cs[c * d + jj] = c'_jj, nb[c] = -|c'|^2 / 2, mu[jj]
+    float* cs = rows;
+    float* nb = cs + k * d;
+    float* mu = nb + k;
+    if (tid < d) {
+        float m = 0.f;
+        for (int c = 0; c < k_active; ++c) m += centers[c * d + tid];
+        mu[tid] = m / (float)k_active;
+    }
+    __syncthreads();
+    for (int i = tid; i < k * d; i += kBlock) cs[i] = centers[i] - mu[i % d];
+    __syncthreads();
+    if (tid < k) {
+        float n2 = 0.f;
+        for (int jj = 0; jj < d; ++jj) n2 = fmaf(cs[tid * d + jj], cs[tid * d + jj], n2);
+        nb[tid] = -0.5f * n2;
+    }
+    __syncthreads();
+    const float mu_a = da < d ? mu[da] : 0.f, mu_b = db < d ? mu[db] : 0.f, mu_8 = d == 9 ? mu[8] : 0.f;
+    // centre-side operands (loop invariant): lane (i = j, g) holds centre 16 cb + i
+    u32x4 ca0[CB], ca1[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        const int c = cb * 16 + j;
+        Split3 a{0.f, 0.f, 0.f}, b{0.f, 0.f, 0.f};
+        float e0 = 0.f, e1 = 0.f, e2 = 0.f;
+        if (c < k_active) {
+            if (da < d) a = split3(cs[c * d + da]);
+            if (db < d) b = split3(cs[c * d + db]);
+            if (has8) {
+                const Split3 e = split3(cs[c * d + 8]);
+                if (g == 0) { e0 = e.h; e1 = e.m; e2 = e.l; }          // x8h * (c8h, c8m, c8l)
+                else        { e0 = e.h; e1 = e.m; e2 = e.h; }          // (x8m, x8m, x8l) * (c8h, c8m, c8h)
+            } else if (g == 2) {
+                const Split3 e = split3(nb[c]);
+                e0 = e.h; e1 = e.m; e2 = e.l;
+            }
+        } else if (g == 2) {
+            e0 = -1.0e30f;                                             // inactive / padding centre: never the maximum
+        }
+        frag_centre(a, b, e0, e1, e2, ca0[cb], ca1[cb]);
+    }
+    __syncthreads();                                                   // the rows region is staged into from here on
+    // point-side selection of the extras, as exact 0/1 weights (no divergent code in the loop)
+    const float w8h0 = (has8 && g == 0) ? 1.f : 0.f;                   // g = 0: (x8h, x8h, x8h)
+    const float w8m = (has8 && g == 1) ? 1.f : 0.f;                    // g = 1: (x8m, x8m, x8l)
+    const float wone = g == 2 ? 1.f : 0.f;                             // g = 2: (1, 1, 1)
+
+    floatx4 acc[CB];                                                   // one-hot accumulate (ACCUM)
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) acc[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const int64_t nblk = (N + kBlock - 1) / kBlock;
+    // Rows travel HBM -> registers -> LDS, one trip AHEAD: the loads of trip t+1 are issued before the tiles of trip t are
+    // scored and land in LDS after the barrier that ends trip t, so their latency hides under the MFMA / argmax work.
+    // Three named float4 registers (576 = 2 x 256 + 64 float4s per trip at d = 9; an indexed array went to scratch).
+    constexpr int NV4 = kBlock * DT / 4;
+    static_assert(NV4 > 2 * kBlock - 1 ? NV4 <= 3 * kBlock : true, "three float4 per thread cover a trip");
+    float4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0, q2 = q0;
+    auto fast_trip = [&](int64_t b) {
+        return b < nblk && (b + 1) * kBlock <= N && (reinterpret_cast<uintptr_t>(feat + b * kBlock * d) & 15u) == 0;
+    };
+    auto issue_loads = [&](int64_t b) {
+        const float4* s4 = reinterpret_cast<const float4*>(feat + b * kBlock * d);
+        q0 = s4[tid];
+        if (tid + kBlock < NV4) q1 = s4[tid + kBlock];
+        if (NV4 > 2 * kBlock && tid + 2 * kBlock < NV4) q2 = s4[tid + 2 * kBlock];
+    };
+    bool prefetched = fast_trip(blockIdx.x);
+    if (prefetched) issue_loads(blockIdx.x);
+    for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+        const int64_t row0 = blk * kBlock;
+        const int nrows = (int)min((int64_t)kBlock, N - row0);
+        const float* src = feat + row0 * d;
+        if (prefetched) {
+            float4* r4 = reinterpret_cast<float4*>(rows);
+            r4[tid] = q0;
+            if (tid + kBlock < NV4) r4[tid + kBlock] = q1;
+            if (NV4 > 2 * kBlock && tid + 2 * kBlock < NV4) r4[tid + 2 * kBlock] = q2;
+        } else {
+            for (int i = tid; i < kBlock * d; i += kBlock) rows[i] = i < nrows * d ? src[i] : 0.f;
+        }
+        prefetched = fast_trip(blk + gridDim.x);
+        if (prefetched) issue_loads(blk + gridDim.x);
+        __syncthreads();
+        // ---- scores + argmax: this wave's 64 points, 16 per tile; lane (j, g) works on point 16 t + j ----
+#pragma unroll 1
+        for (int t = 0; t < 4; ++t) {
+            const int p = wave * kWave + t * 16 + j;
+            const float* xr = rows + p * d;
+            Split3 a{0.f, 0.f, 0.f}, b{0.f, 0.f, 0.f};
+            if (da < d) a = split3(xr[da] - mu_a);
+            if (db < d) b = split3(xr[db] - mu_b);
+            Split3 e{0.f, 0.f, 0.f};
+            if (d == 9) e = split3(xr[8] - mu_8);
+            const float e0 = fmaf(w8h0, e.h, fmaf(w8m, e.m, wone));
+            const float e2 = fmaf(w8h0, e.h, fmaf(w8m, e.l, wone));
+            u32x4 pb0, pb1;
+            frag_point(a, b, e0, e0, e2, pb0, pb1);
+            float best = -3.4e38f;
+            int best_rel = 0;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                floatx4 sc = {0.f, 0.f, 0.f, 0.f};
+                sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ca0[cb]), __builtin_bit_cast(bf16x8_t, pb0), sc, 0, 0, 0);
+                sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ca1[cb]), __builtin_bit_cast(bf16x8_t, pb1), sc, 0, 0, 0);
+                // lane (point j, group g) now holds the scores of centres 16 cb + 4 g + r, r = 0..3: ascending index
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (sc[r] > best) { best = sc[r]; best_rel = cb * 16 + r; }
+            }
+            int best_id = best_rel + 4 * g;
+            // merge the four lane groups of a point: higher score, on equal score the lower index
+            {
+                auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(best), __float_as_uint(best), false, false);
+                auto i16 = __builtin_amdgcn_permlane16_swap((unsigned)best_id, (unsigned)best_id, false, false);
+                const float s0 = __uint_as_float(r16[0]), s1 = __uint_as_float(r16[1]);
+                const int i0 = (int)i16[0], i1 = (int)i16[1];
+                const bool take1 = s1 > s0 || (s1 == s0 && i1 < i0);
+                best = take1 ? s1 : s0;
+                best_id = take1 ? i1 : i0;
+                auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false);
+                auto i32 = __builtin_amdgcn_permlane32_swap((unsigned)best_id, (unsigned)best_id, false, false);
+                const float t0 = __uint_as_float(r32[0]), t1 = __uint_as_float(r32[1]);
+                const int j0 = (int)i32[0], j1 = (int)i32[1];
+                const bool take = t1 > t0 || (t1 == t0 && j1 < j0);
+                best_id = take ? j1 : j0;
+            }
+            if (g == 0) {
+                const bool live = t * 16 + j + wave * kWave < nrows;
+                if (ACCUM) ids_s[p] = live ? best_id : -1;
+                else if (live) ids_out[row0 + p] = (int64_t)best_id + id_offset;
+            }
+        }
+        if (ACCUM) {
+            __syncthreads();
+            // one_hot(ids)^T @ rows on the bf16 path (as kmeans_accum_bf16_kernel: 32 points per MFMA group, three exact
+            // bf16 terms per row value), with cheaper operand construction: the row values are split by truncation
+            // (and / subtract, full-rate) and packed with v_perm; the one-hot factor of two points is ONE packed 16-bit
+            // expression per dword: (id ^ target) -> min(., 1) -> 0x3F80 - 0x3F80 * that   (v_xor, v_pk_min_u16, v_pk_mad_u16)
+#pragma unroll
+            for (int h = 0; h < kWave / 32; ++h) {
+                const int p0 = wave * kWave + h * 32 + g * 8;
+                unsigned idp[4];
+                u32x4 bh, bm, bl;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ia = ids_s[p0 + 2 * q], ib = ids_s[p0 + 2 * q + 1];
+                    idp[q] = ((unsigned)ia & 0xFFFFu) | ((unsigned)ib << 16);          // -1 -> 0xFFFF: matches no centre
+                    float xa = 0.f, xb = 0.f;
+                    if (ia >= 0) xa = j < d ? rows[(p0 + 2 * q) * d + j] : (j == d ? 1.0f : 0.f);
+                    if (ib >= 0) xb = j < d ? rows[(p0 + 2 * q + 1) * d + j] : (j == d ? 1.0f : 0.f);
+                    const Split3 sa = split3(xa), sb = split3(xb);
+                    bh[q] = pack_hi16(sa.h, sb.h); bm[q] = pack_hi16(sa.m, sb.m); bl[q] = pack_hi16(sa.l, sb.l);
+                }
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+                    const unsigned tgt = (unsigned)(cb * 16 + j) * 0x00010001u;
+                    u32x4 a;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        // (asm: hipcc rewrites the C form into two 16-bit compares + two selects + a merge per dword)
+                        unsigned ne, one;
+                        asm("v_pk_min_u16 %0, %1, %2" : "=v"(ne) : "v"(idp[q] ^ tgt), "v"(0x00010001u));
+                        asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(one) : "v"(ne), "v"(0xC080C080u), "v"(0x3F803F80u));   // bf16 1.0 where equal
+                        a[q] = one;
+                    }
+                    const bf16x8_t av = __builtin_bit_cast(bf16x8_t, a);
+                    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8_t, bh), acc[cb], 0, 0, 0);
+                    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8_t, bm), acc[cb], 0, 0, 0);
+                    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8_t, bl), acc[cb], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (ACCUM) {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                wtab[(wave * CB * 16 + cb * 16 + g * 4 + r) * 16 + j] = acc[cb][r];
+        __syncthreads();
+        float* out = partials + (size_t)blockIdx.x * k * (d + 1);
+        for (int e = tid; e < k * (d + 1); e += kBlock) {
+            const int c = e / (d + 1), col = e - c * (d + 1);
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < kBlock / kWave; ++w) sum += wtab[(w * CB * 16 + c) * 16 + col];   // fixed order
+            out[e] = sum;
+        }
+    }
+}
+
 // ---- fallback for shapes outside the MFMA tiling: per-workgroup LDS accumulators ---------------------------------
 template <bool ACCUM>
 __global__ __launch_bounds__(kBlock) void kmeans_lds_pass_kernel(const float* __restrict__ feat, int64_t N, int d,
@@ -542,9 +796,80 @@ __global__ __launch_bounds__(1024) void kmeans_finalize_kernel(const float* __re
     }
 }
 
+// Stages 1 + 2 in ONE launch (round 3): every workgroup sums its slice as kmeans_reduce_kernel does, then draws a ticket; the
+// workgroup that draws the last one applies kmeans_finalize_kernel's step to the 64 slices.  Same summation orders -> the
+// same bits as the two-launch form.  Hand-off per the MI355X guide (Guideline 16): slice stores -> every storing wave's
+// s_waitcnt vmcnt(0) -> workgroup barrier -> one lane's agent-scope release fence (+ vmcnt(0)) -> relaxed agent-scope
+// ticket; the last arriver: agent-scope acquire fence -> vmcnt(0) -> barrier -> plain loads.  The ticket word is reset by
+// the last arriver (and zeroed at the start of every Lloyd call).
+__global__ __launch_bounds__(kBlock) void kmeans_reduce_finalize_kernel(const float* __restrict__ partials, int nblocks, int k,
+                                                                        int d, float* __restrict__ slices, float eps_total,
+                                                                        float* __restrict__ counts_state,
+                                                                        float* __restrict__ centers,
+                                                                        unsigned int* __restrict__ ticket) {
+    extern __shared__ float tot[];            // [k*(d+1)] (last arriver only)
+    __shared__ unsigned int s_last;
+    const int stride = k * (d + 1);
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e < stride) {
+        const int per = (nblocks + kSlices - 1) / kSlices;
+        const int b0 = blockIdx.y * per, b1 = min(nblocks, b0 + per);
+        float s = 0.f;
+        int b = b0;
+        for (; b + 8 <= b1; b += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partials[(size_t)(b + u) * stride + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; b < b1; ++b) s += partials[(size_t)b * stride + e];
+        slices[(size_t)blockIdx.y * stride + e] = s;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int total = gridDim.x * gridDim.y;
+        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == total - 1u) ? 1u : 0u;
+        if (s_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // ready for the next launch
+        }
+    }
+    __syncthreads();
+    if (!s_last) return;
+    for (int i = threadIdx.x; i < stride; i += kBlock) {
+        // all 64 slice values of an element in flight at once (one workgroup does this: latency, not bandwidth), summed in
+        // slice order -- the order of the two-launch form
+        float v[kSlices];
+#pragma unroll
+        for (int sl = 0; sl < kSlices; ++sl) v[sl] = slices[(size_t)sl * stride + i];
+        float s = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < kSlices; ++sl) s += v[sl];
+        tot[i] = s;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < k * d; i += kBlock) {
+        const int c = i / d, jj = i - c * d;
+        const float cnt = counts_state[c] + (tot[c * (d + 1) + d] + eps_total);
+        centers[i] = tot[c * (d + 1) + jj] / cnt;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < k; c += kBlock) {
+        const float cnt = counts_state[c] + (tot[c * (d + 1) + d] + eps_total);
+        counts_state[c] = cnt > 0.1f ? 0.f : cnt;
+    }
+}
+
+// p[0..n) = v, p[n] = 0 (the reduce kernel's ticket word sits right behind the counts)
 __global__ __launch_bounds__(kBlock) void fill_kernel(float* p, int n, float v) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i < n) p[i] = v;
+    if (i <= n) p[i] = i < n ? v : 0.f;
 }
 
 __global__ __launch_bounds__(kBlock) void kmeans_gather_kernel(const float* __restrict__ centers,
@@ -630,9 +955,30 @@ int launch_mfma_p(int nb, hipStream_t s, const float* feat, int64_t N, int d, co
     return OGS_OK;
 }
 
+inline int km_gemm() {          // OGS_KM_GEMM=0: the direct-difference distance loop on the VALU (round 2)
+    static const int v = [] { const char* e = getenv("OGS_KM_GEMM"); return (e && atoi(e) == 0) ? 0 : 1; }();
+    return v;
+}
+
 template <int CB, bool ACCUM, int DT>
 int launch_mfma_d(int nb, hipStream_t s, const float* feat, int64_t N, int d, const float* centers, int k, int k_active,
                   int64_t* ids_out, int64_t id_offset, float* partials) {
+    if constexpr ((DT == 6 || DT == 9) && CB <= 4) {
+        if (km_gemm()) {
+            const size_t setup = (size_t)k * DT + k + DT;                      // shifted centres, biases, mean (before the first trip)
+            size_t body = (size_t)kBlock * DT + kBlock;
+            const size_t wtab = ACCUM ? (size_t)4 * CB * 16 * 16 : 0;
+            body = body > wtab ? body : wtab;
+            const size_t lds = sizeof(float) * (body > setup ? body : setup);
+            int rc = allow_lds(kmeans_gemm_pass_kernel<CB, ACCUM, DT>, lds);
+            if (rc != OGS_OK) return rc;
+            OGS_LAUNCH_NAMED(ACCUM ? "kmeans_gemm_pass_kernel<accum>" : "kmeans_gemm_pass_kernel<assign>",
+                             (kmeans_gemm_pass_kernel<CB, ACCUM, DT>), dim3(nb), dim3(kBlock), lds, s, feat, N, centers, k,
+                             k_active, ids_out, id_offset, partials);
+            OGS_LAUNCH_CHECK(0, s);
+            return OGS_OK;
+        }
+    }
     if constexpr (DT > 0 && ACCUM) {
         if (km_ppl() == 1 && km_pipelined()) {
             const size_t rows = (size_t)2 * kBlock * DT + 2 * kBlock, wtab = (size_t)4 * CB * 16 * 16;
@@ -696,7 +1042,7 @@ using namespace ogs;
 extern "C" {
 
 size_t ogs_kmeans_tmp_bytes(int64_t N, int32_t d, int32_t k) {
-    return align_up((size_t)pass_blocks(N) * k * (d + 1) * sizeof(float)) + align_up((size_t)k * sizeof(float)) +
+    return align_up((size_t)pass_blocks(N) * k * (d + 1) * sizeof(float)) + align_up((size_t)(k + 1) * sizeof(float)) +
            align_up((size_t)kSlices * k * (d + 1) * sizeof(float));
 }
 
@@ -723,21 +1069,19 @@ int ogs_kmeans_lloyd(const float* feat, int64_t N, int32_t d, float* centers, in
     const int nb = pass_blocks(N);
     float* partials = static_cast<float*>(tmp);
     float* counts = reinterpret_cast<float*>(static_cast<char*>(tmp) + align_up((size_t)nb * k * (d + 1) * sizeof(float)));
-    float* slices = reinterpret_cast<float*>(reinterpret_cast<char*>(counts) + align_up((size_t)k * sizeof(float)));
+    float* slices = reinterpret_cast<float*>(reinterpret_cast<char*>(counts) + align_up((size_t)(k + 1) * sizeof(float)));
+    unsigned int* ticket = reinterpret_cast<unsigned int*>(counts + k);          // zeroed here, reset by each last arriver
     const int stride = k * (d + 1);
-    OGS_LAUNCH(fill_kernel, dim3((k + kBlock - 1) / kBlock), dim3(kBlock), 0, s, counts, k, 1e-6f);
+    OGS_LAUNCH(fill_kernel, dim3((k + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, s, counts, k, 1e-6f);   // counts + ticket = 0
     OGS_LAUNCH_CHECK(0, s);
     const size_t fin_lds = (size_t)k * (d + 1) * sizeof(float);
-    rc = allow_lds(kmeans_finalize_kernel, fin_lds);
+    rc = allow_lds(kmeans_reduce_finalize_kernel, fin_lds);
     if (rc != OGS_OK) return rc;
     for (int it = 0; it < iters; ++it) {
         rc = launch_pass<true>(nb, s, feat, N, d, centers, k, k_active, nullptr, 0, partials);
         if (rc != OGS_OK) return rc;
-        OGS_LAUNCH(kmeans_reduce_kernel, dim3((stride + kBlock - 1) / kBlock, kSlices), dim3(kBlock), 0, s,
-                   (const float*)partials, nb, stride, slices);
-        OGS_LAUNCH_CHECK(0, s);
-        OGS_LAUNCH(kmeans_finalize_kernel, dim3(1), dim3(1024), fin_lds, s, (const float*)slices, kSlices, k, d,
-                   (float)nchunks * 1e-6f, counts, centers, (float*)nullptr);
+        OGS_LAUNCH(kmeans_reduce_finalize_kernel, dim3((stride + kBlock - 1) / kBlock, kSlices), dim3(kBlock), fin_lds, s,
+                   (const float*)partials, nb, k, d, slices, (float)nchunks * 1e-6f, counts, centers, ticket);
         OGS_LAUNCH_CHECK(0, s);
     }
     if (N > 0) {

@@ -358,6 +358,10 @@ constexpr int kReachBit = 31;                           // Gaussian ids are < 2^
 constexpr uint32_t kGidMask = (1u << kReachBit) - 1u;
 // max over the box d in [xlo,xhi] x [ylo,yhi] of  -0.5*(A dx^2 + C dy^2) - B dx dy   (A, C > 0, AC - B^2 > 0)
 // nbA = -B / A, nbC = -B / C: the slopes of the 1-D maximisers (per Gaussian, so a caller with many boxes divides once)
+// The result is an UPPER bound that also covers fp32 rounding: for a needle-shaped Gaussian far from its centre the terms
+// A dx^2, C dy^2, 2 B dx dy reach 1e5 .. 1e6 while their sum is O(1) -- the cancellation error of this evaluation AND of the
+// blend kernels' own evaluation of the power at a pixel (each a few ulp of the largest term) can exceed the fixed
+// kThrMargin.  Slack: 8e-7 x the largest possible term magnitude over the box.
 __device__ __forceinline__ float max_power_in_box(float A, float B, float Cc, float nbA, float nbC, float xlo, float xhi,
                                                   float ylo, float yhi) {
     if (xlo <= 0.f && xhi >= 0.f && ylo <= 0.f && yhi >= 0.f) return 0.f;
@@ -367,7 +371,8 @@ __device__ __forceinline__ float max_power_in_box(float A, float B, float Cc, fl
     m = fmaxf(m, q(xhi, fminf(fmaxf(nbC * xhi, ylo), yhi)));
     m = fmaxf(m, q(fminf(fmaxf(nbA * ylo, xlo), xhi), ylo));
     m = fmaxf(m, q(fminf(fmaxf(nbA * yhi, xlo), xhi), yhi));
-    return m;
+    const float X = fmaxf(fabsf(xlo), fabsf(xhi)), Y = fmaxf(fabsf(ylo), fabsf(yhi));
+    return m + 8e-7f * (0.5f * (A * X * X + Cc * Y * Y) + fabsf(B) * X * Y);
 }
 __device__ __forceinline__ float max_power_in_box(float A, float B, float Cc, float xlo, float xhi, float ylo,
                                                   float yhi) {

@@ -460,7 +460,44 @@ def _adversarial_scene(kind, P, W, H, f, seed):
         sc.opacities[::7] = 0.02
     elif kind == "depth_ties":          # many exactly equal depths: order must fall back to the Gaussian index
         sc.means3D[:, 2] = torch.round(sc.means3D[:, 2])
+    elif kind == "needles":             # hundreds of pixels long, ~0.55 px thin (the 0.3 dilation), diagonal: the terms of the
+        # quadratic form reach 1e5 .. 1e6 far from the centre while their sum stays O(1) (the reach test's
+        # fixed log-space margin is smaller than the fp32 cancellation error there)
+        sc.means3D[:, 2] = torch.rand(P, generator=g) * 2 + 3
+        sc.means3D[:, 0] = (torch.rand(P, generator=g) - 0.5) * 2.0 * sc.means3D[:, 2] * (W / (2 * f))
+        sc.means3D[:, 1] = (torch.rand(P, generator=g) - 0.5) * 2.0 * sc.means3D[:, 2] * (H / (2 * f))
+        sc.scales[:, 0] = 3.0 + torch.rand(P, generator=g) * 3.0
+        sc.scales[:, 1:] = 1e-4
+        ang = (torch.rand(P, generator=g) - 0.5) * 0.5 + 0.785398                 # about the view axis, around 45 degrees
+        sc.rotations[:] = torch.stack([torch.cos(ang / 2), torch.zeros(P), torch.zeros(P), torch.sin(ang / 2)], dim=1)
+        sc.opacities[:] = 0.5 + 0.49 * torch.rand(P, 1, generator=g)
     return sc, cam
+
+
+def test_reach_flags_on_needle_gaussians(gpu_device):
+    """The (Gaussian, tile) reach test of duplicate_kernel must stay conservative where fp32 cancellation is at its worst:
+    needle-shaped splats (sigma ratio ~500 : 1) far from their centre.  Every pair it drops must fail the reach predicate in
+    float64 on all 256 pixel centres of its tile; binning stays bit-exact; and a substantial share IS dropped (a needle
+    crosses its ceil(3 sigma) square of tiles along one diagonal only)."""
+    from oracle import raster_oracle as ro
+    W, H, f, P = 640, 480, 300.0, 160
+    sc, cam = _adversarial_scene("needles", P, W, H, f, seed=43)
+    inp = helpers.oracle_inputs(sc, cam, use_sh=True)
+    g = ro.preprocess(inp["means3D"], inp["opacities"], inp["viewmatrix"], inp["projmatrix"], inp["campos"], W, H, W / (2 * f),
+                      H / (2 * f), scales=inp["scales"], rotations=inp["rotations"], shs=inp["shs"], sh_degree=3)
+    b = ro.bin_tiles(g, W, H)
+    lam = 0.5 * (g.conic[:, 0] + g.conic[:, 2])
+    assert int(g.radii.max()) > 300 and float((lam[g.radii > 0]).max()) > 1.0          # long AND thin in pixels
+    (color, radii, depth, alpha), _ = helpers.hip_forward(inp, cam, (0.0, 0.0, 0.0), 3, gpu_device, requires_grad=True)
+    keys, ranges, ncontrib, plist = helpers.hip_export_binning(color)
+    np.testing.assert_array_equal(radii.cpu().numpy(), g.radii)
+    np.testing.assert_array_equal(keys, b.keys_sorted)
+    np.testing.assert_array_equal(plist, b.point_list)
+    flags = helpers.LAST_REACH_FLAGS[0]
+    n_dropped = helpers.assert_reach_flags_keep_every_contributor(flags, keys, plist, g, W, H)
+    assert n_dropped > 0.5 * len(plist), (n_dropped, len(plist))
+    a = alpha.detach().cpu().numpy()
+    assert np.isfinite(color.detach().cpu().numpy()).all() and a.min() >= 0.0 and a.max() <= 1.0 + 1e-5 and a.max() > 0.3
 
 
 @pytest.mark.parametrize("kind,P,W,H", [("long_lists", 3000, 48, 32), ("faint_and_opaque", 2000, 128, 80),
