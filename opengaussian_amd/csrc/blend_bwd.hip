@@ -51,15 +51,6 @@ struct WaveFoldLds {
     float w[kFoldRows * kFoldStride];
 };
 
-template <int N>
-__device__ __forceinline__ float row_bcast(float v) {     // lane n of every row of 16 lanes -> the whole row
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x150 + N, 0xF, 0xF, false));
-}
-template <int N>
-__device__ __forceinline__ uint32_t row_bcast_u(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x150 + N, 0xF, 0xF, false);
-}
-
 // WIDE: all sixteen LDS reads in flight and four independent MFMA chains (the features-only kernel has the
 // registers for it and, with little VALU work per entry, feels the latency of a serial flush the most)
 template <int NCH, int SLOT0, int GS, typename ACC, bool WIDE = false>
@@ -112,8 +103,7 @@ struct RankOneFold {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int e = 4 * kq + r;
-            // entry e sits in lane r of row kq of the stash register (push): DPP row broadcast instead of ds_bpermute
-            const uint32_t g = r == 0 ? row_bcast_u<0>(gidv) : r == 1 ? row_bcast_u<1>(gidv) : r == 2 ? row_bcast_u<2>(gidv) : row_bcast_u<3>(gidv);
+            const uint32_t g = (uint32_t)__builtin_amdgcn_ds_bpermute(e * 4, (int)gidv);
             // 32-bit element offset from the (uniform) record array: SGPR-base addressing
             const uint32_t off = g * (uint32_t)GS + (uint32_t)(SLOT0 + m);
             if (e < cnt && m < NCH && !skip_atomics) atomicAdd(grad_rec + off, (ACC)d[r]);
@@ -131,10 +121,9 @@ struct RankOneFold {
             "s_mov_b32 m0, %3\n\t"
             "s_nop 0\n\t"
             "v_writelane_b32 %0, %2, m0\n\t"
-            "s_nop 1\n\t"                       // the flush reads the stash through DPP: two wait states after a VALU write
             "s_mov_b32 m0, %1"
             : "+v"(gidv), "=&s"(m0_saved)
-            : "s"(g), "s"(((cnt >> 2) << 4) | (cnt & 3)));                         // lane (entry & 3) of row (entry >> 2)
+            : "s"(g), "s"(cnt));
         ++cnt;
         if (cnt == kFoldRows) flush(grad_rec, lane);
     }
@@ -164,6 +153,10 @@ struct PairFoldLds {
     float t[16 * kPairStride];
 };
 
+template <int N>
+__device__ __forceinline__ float row_bcast(float v) {     // lane n of every row of 16 lanes -> the whole row
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x150 + N, 0xF, 0xF, false));
+}
 
 template <int C, bool DEPTH, int GS, typename ACC>
 struct PairFold {
@@ -220,11 +213,9 @@ struct PairFold {
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
             const int e = 2 * kq + rr;
-            // entry e = 2 kq + rr sits in lane rr of row kq of the stash registers (push): a DPP row broadcast (4 issue
-            // cycles) instead of a ds_bpermute (24) for each of the three values
-            const uint32_t g = rr == 0 ? row_bcast_u<0>(gidv) : row_bcast_u<1>(gidv);
-            const float a = (rr == 0 ? row_bcast<0>(mxv) : row_bcast<1>(mxv)) - x0;
-            const float b = (rr == 0 ? row_bcast<0>(myv) : row_bcast<1>(myv)) - y0;
+            const uint32_t g = (uint32_t)__builtin_amdgcn_ds_bpermute(e * 4, (int)gidv);
+            const float a = __int_as_float(__builtin_amdgcn_ds_bpermute(e * 4, __float_as_int(mxv))) - x0;
+            const float b = __int_as_float(__builtin_amdgcn_ds_bpermute(e * 4, __float_as_int(myv))) - y0;
             const float own = d[2 + rr];
             const float M0 = row_bcast<kSlotMoments>(own), Mu = row_bcast<kSlotMoments + 1>(own),
                         Mv = row_bcast<kSlotMoments + 2>(own);
@@ -257,10 +248,9 @@ struct PairFold {
             "v_writelane_b32 %0, %4, m0\n\t"
             "v_writelane_b32 %1, %5, m0\n\t"
             "v_writelane_b32 %2, %6, m0\n\t"
-            "s_nop 1\n\t"                       // the flush reads the stash through DPP: two wait states after a VALU write
             "s_mov_b32 m0, %3"
             : "+v"(gidv), "+v"(mxv), "+v"(myv), "=&s"(m0_saved)
-            : "s"(g), "s"(mx), "s"(my), "s"(((cnt >> 1) << 4) | (cnt & 1)));        // lane (entry & 1) of row (entry >> 1)
+            : "s"(g), "s"(mx), "s"(my), "s"(cnt));
         ++cnt;
         if (cnt == 8) flush(grad_rec, lane);
     }

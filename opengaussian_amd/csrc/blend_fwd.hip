@@ -216,32 +216,23 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
         const float power = blend_power(cur[2], cur[3], cur[4], dx, dy);
         const bool cand = fabsf(power + cur[5]) <= cur[5];
         if (__ballot(cand) != 0ull) {
-            bool any_stop = false;
+            bool stop = false;
             if (cand) {
                 float alpha = fminf(0.99f, cur[6] * __expf(power));
                 alpha = alpha >= kAlphaMin ? alpha : 0.f;
                 const float test_T = T * (1.0f - alpha);
-                const bool stop = test_T < 0.0001f;            // this entry is NOT applied (A.3)
-                float w = alpha * T;
-                // A pixel saturates once in its life, so most entries stop no lane of the wave: then no select is needed at
-                // all (three v_cndmask with an SGPR-pair mask = 12 issue cycles of the ~120 an entry costs; same arithmetic
-                // on both paths: the images are bit for bit the old ones)
-                if (__ballot(stop) == 0ull) {
-                    T = test_T;
-                } else {
-                    w = stop ? 0.f : w;
-                    T = stop ? T : test_T;
-                    fxe = stop ? kFar : fxe;
-                    any_stop = true;
-                }
+                stop = test_T < 0.0001f;                       // this entry is NOT applied (A.3)
+                const float w = stop ? 0.f : alpha * T;
                 const v2f w2 = {w, w};
 #pragma unroll
                 for (int k = 0; k < NPF; ++k)       // explicit FMA (the tiny pass reproduces these bits)
                     accp[k] = __builtin_elementwise_fma((v2f){rec_j.feat(2 * k), rec_j.feat(2 * k + 1)}, w2, accp[k]);
                 wacc += w;
+                T = stop ? T : test_T;
                 last = w > 0.f ? (uint32_t)j + 1u : last;
+                fxe = stop ? kFar : fxe;
             }
-            if (__builtin_amdgcn_readfirstlane(__ballot(any_stop) != 0ull)) all_done = __ballot(fxe < kFarTest) == 0ull;   // whole wave finished?
+            if (__ballot(stop) != 0ull) all_done = __ballot(fxe < kFarTest) == 0ull;   // whole wave finished?
         }
     };
     // Software pipeline over the wave-uniform index stream, in BATCHES of two records.  SMEM returns out of order,
@@ -280,6 +271,184 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
         out_alpha[pix] = wacc;
         n_contrib[pix] = last;          // index into the QUADRANT stream (+1); see export_n_contrib_kernel
         final_T[pix] = T;               // the backward starts its T recursion from this, not from 1 - alpha
+    }
+    pf.retire(n_contrib, W);
+}
+
+// ---- forward blend, one list per 4x4 pixel block (round 3) -------------------------------------------------------------
+// The quadrant walk above keeps ~51 % of its lanes busy (an entry that reaches an 8x8 quadrant touches half of its pixels
+// on average) and pays 4 issue cycles for nearly every vector instruction, because the entry's record sits in SGPRs
+// (profiles/r03_valu_issue_price_list.json: any SGPR operand halves the issue rate).  Here a wave still owns a quadrant
+// and walks the same quadrant index stream, but in CHUNKS of 64 entries:
+//   1. lane e gathers record e of the chunk with vector loads (L2 hits: the prefetch at kernel entry pulled the tile's
+//      records in), tests it against the four 4x4 blocks of the quadrant (the exact box-vs-ellipse test of pack, on a
+//      4x4 box) and parks the record in the wave's LDS region;
+//   2. four ballots + prefix popcounts turn the test bits into four compacted lists (LDS), one per DPP row;
+//   3. the four rows of the wave -- row r = the 16 pixels of block r -- walk THEIR lists side by side: per step a row reads
+//      its next record from LDS into VGPRs (four different records per ds_read_b128, one LDS cycle per row) and every
+//      operand of the per-pixel arithmetic is a VGPR.
+// The arithmetic per (pixel, entry) is the quadrant kernel's, in the same order (blend_power, the same candidate window,
+// the same FMAs): a skipped (entry, block) pair is one every pixel of the block would have skipped, so images,
+// n_contrib (still the 1-based position in the QUADRANT stream: the backward kernels are unchanged) and final_T are bit
+// for bit those of blend_forward_kernel.
+template <int C>
+struct RowRec {          // one record in VGPRs
+    static constexpr int NV4 = stream_vec4(C);
+    float4 v[NV4];
+    __device__ __forceinline__ void load_lds(const float4* __restrict__ p) {
+#pragma unroll
+        for (int k = 0; k < NV4; ++k) v[k] = p[k];
+    }
+    __device__ __forceinline__ float at(int i) const {      // i compile-time after unrolling
+        const float4 q = v[i >> 2];
+        return (i & 3) == 0 ? q.x : (i & 3) == 1 ? q.y : (i & 3) == 2 ? q.z : q.w;
+    }
+    __device__ __forceinline__ float feat(int c) const { return at(8 + c); }
+};
+
+template <int C>
+__global__ __launch_bounds__(kBlock) void blend_forward_rows_kernel(
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ qcount, const float* __restrict__ stream,
+    const uint32_t* __restrict__ quad_list, int W, int H, int gx, int tiles, const float* __restrict__ bg, float* __restrict__ out_color,
+    float* __restrict__ out_depth, float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib,
+    float* __restrict__ final_T, int pf_lines, const uint32_t* __restrict__ tile_order) {
+    constexpr int NV4 = stream_vec4(C);
+    constexpr int RS = NV4 * 4;                  // floats per stream record
+    constexpr int kSlots = 65;                   // 64 chunk entries + the dummy that a finished row keeps reading
+    constexpr int kListLen = 72;                 // 64 + slack for the two-ahead index reads
+    __shared__ float4 s_rec[kBlock / kWave][kSlots * NV4];
+    __shared__ uint32_t s_list[kBlock / kWave][4][kListLen];
+    const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
+    const int img = tile / tiles, timg = tile - img * tiles;
+    const int tx = timg % gx, ty = timg / gx;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row = lane >> 4, l16 = lane & 15;
+    const int qx0 = tx * kTile + (wave & 1) * 8, qy0 = ty * kTile + (wave >> 1) * 8;       // quadrant origin
+    const int px = qx0 + 4 * (row & 1) + (l16 & 3);
+    const int py = qy0 + 4 * (row >> 1) + (l16 >> 2);
+    const bool inside = px < W && py < H;
+    const float fy = (float)py;
+
+    const uint2 range = ranges[tile];
+    const int n_tile = (int)(range.y - range.x);
+    const int n = (int)qcount[tile * 5 + wave];
+    const int n_kept = (int)qcount[tile * 5 + 4];
+    const float* __restrict__ tb = stream + (size_t)range.x * RS;
+    const uint32_t* __restrict__ qi = quad_list + ((size_t)range.x * 5 + (size_t)wave * n_tile);
+    const uint32_t lim = n_kept > 0 ? (uint32_t)n_kept - 1u : 0u;
+    RecordPrefetch pf;
+    pf.issue(tb, n_kept, RS, tid, pf_lines);
+
+    float4* __restrict__ recs = s_rec[wave];
+    uint32_t* __restrict__ mylist = s_list[wave][row];
+    if (lane == 0) {
+        // dummy record: h < 0 makes |power + h| <= h false for every pixel
+#pragma unroll
+        for (int k = 0; k < NV4; ++k) recs[64 * NV4 + k] = float4{0.f, 0.f, 0.f, 0.f};
+        recs[64 * NV4 + 1] = float4{0.f, -1.f, 0.f, 0.f};                    // fields 4..7: c2, h = -1, opacity, id
+    }
+    float fxe = inside ? (float)px : kFar;
+    float T = 1.0f;
+    constexpr int NPF = (C + 2) / 2;
+    v2f accp[NPF];
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) accp[k] = (v2f){0.f, 0.f};
+    float wacc = 0.f;
+    uint32_t last = 0;
+    bool all_done = false;
+
+    auto consume = [&](const RowRec<C>& rec, uint32_t jplus1) {
+        const float dx = rec.at(0) - fxe, dy = rec.at(1) - fy;
+        const float power = blend_power(rec.at(2), rec.at(3), rec.at(4), dx, dy);
+        const float h = rec.at(5);
+        const bool cand = fabsf(power + h) <= h;
+        if (__ballot(cand) != 0ull) {
+            bool stop = false;
+            if (cand) {
+                float alpha = fminf(0.99f, rec.at(6) * __expf(power));
+                alpha = alpha >= kAlphaMin ? alpha : 0.f;
+                const float test_T = T * (1.0f - alpha);
+                stop = test_T < 0.0001f;
+                const float w = stop ? 0.f : alpha * T;
+                const v2f w2 = {w, w};
+#pragma unroll
+                for (int k = 0; k < NPF; ++k)
+                    accp[k] = __builtin_elementwise_fma((v2f){rec.feat(2 * k), rec.feat(2 * k + 1)}, w2, accp[k]);
+                wacc += w;
+                T = stop ? T : test_T;
+                last = w > 0.f ? jplus1 : last;
+                fxe = stop ? kFar : fxe;
+            }
+            if (__ballot(stop) != 0ull) all_done = __ballot(fxe < kFarTest) == 0ull;
+        }
+    };
+
+    const float bx0 = (float)(qx0 + 4 * 0), by0 = (float)qy0;
+    for (int c0 = 0; c0 < n && !all_done; c0 += kWave) {
+        const int cnt = min(kWave, n - c0);
+        // ---- 1. gather, test, park ----
+        const bool have = lane < cnt;
+        const uint32_t ridx = have ? min(qi[c0 + lane], lim) : 0u;
+        const float4* __restrict__ rp = reinterpret_cast<const float4*>(tb + (size_t)ridx * RS);
+        float4 r[NV4];
+#pragma unroll
+        for (int k = 0; k < NV4; ++k) r[k] = rp[k];
+#pragma unroll
+        for (int k = 0; k < NV4; ++k) recs[lane * NV4 + k] = r[k];
+        bool reach[4];
+        {
+            const float gxp = r[0].x, gyp = r[0].y;
+            const float A = -2.f * r[0].z, B = -r[0].w, Cc = -2.f * r[1].x, thr = -2.f * r[1].y;
+            const float nbA = -B / A, nbC = -B / Cc;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const float ox = bx0 + 4.f * (float)(b & 1), oy = by0 + 4.f * (float)(b >> 1);
+                const float m = max_power_in_box(A, B, Cc, nbA, nbC, gxp - ox - 3.f, gxp - ox, gyp - oy - 3.f, gyp - oy);
+                reach[b] = have && m >= thr;
+            }
+        }
+        // ---- 2. four compacted lists (row b's list: chunk slots that can reach block b), padded with the dummy ----
+#pragma unroll
+        for (int b = 0; b < 4; ++b) s_list[wave][b][lane] = 64u;
+        if (lane < kListLen - kWave) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) s_list[wave][b][kWave + lane] = 64u;
+        }
+        int maxlen = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint64_t mask = __ballot(reach[b]);
+            const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            if (reach[b]) s_list[wave][b][pos] = (uint32_t)lane;
+            maxlen = max(maxlen, (int)__popcll(mask));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- 3. the four rows walk their lists; records two register sets, indices two steps ahead ----
+        RowRec<C> ra, rb;
+        uint32_t e0 = mylist[0], e1 = mylist[1];
+        ra.load_lds(recs + e0 * NV4);
+        for (int t = 0; t < maxlen && !all_done; t += 2) {
+            const uint32_t e2 = mylist[t + 2], e3 = mylist[t + 3];
+            rb.load_lds(recs + e1 * NV4);
+            consume(ra, (uint32_t)c0 + e0 + 1u);
+            ra.load_lds(recs + e2 * NV4);
+            if (t + 1 < maxlen) consume(rb, (uint32_t)c0 + e1 + 1u);
+            e0 = e2; e1 = e3;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    if (inside) {
+        const size_t plane = (size_t)W * H;
+        const size_t pix = (size_t)img * plane + (size_t)py * W + px;
+        float* oc = out_color + (size_t)img * (C - 1) * plane;
+#pragma unroll
+        for (int c = 0; c < C; ++c) oc[c * plane + pix] = ((c & 1) ? accp[c / 2].y : accp[c / 2].x) + T * bg[c];
+        out_depth[pix] = (C & 1) ? accp[C / 2].y : accp[C / 2].x;
+        out_alpha[pix] = wacc;
+        n_contrib[pix] = last;
+        final_T[pix] = T;
     }
     pf.retire(n_contrib, W);
 }
@@ -536,6 +705,12 @@ __global__ __launch_bounds__(kOrderThreads) void tile_order_kernel(const uint2* 
     }
 }
 
+// the per-4x4-block forward (blend_forward_rows_kernel) is the default; OGS_BLEND_ROWS=0: the quadrant walk (A-B runs)
+static bool blend_rows_enabled() {
+    static const bool v = [] { const char* e = getenv("OGS_BLEND_ROWS"); return !(e && atoi(e) == 0); }();
+    return v;
+}
+
 template <int C>
 int launch_c(const OgsRasterFwdArgs& a, const GeomState& gs, const ImageState& is, int64_t D, hipStream_t s) {
     const int gx = (a.W + kTile - 1) / kTile, gy = (a.H + kTile - 1) / kTile;
@@ -554,6 +729,16 @@ int launch_c(const OgsRasterFwdArgs& a, const GeomState& gs, const ImageState& i
     }
     static constexpr const char* const kNames[4] = {"blend_forward_kernel<3>", "blend_forward_kernel<6>",
                                                     "blend_forward_kernel<9>", "blend_forward_kernel<12>"};
+    if (blend_rows_enabled()) {
+        static constexpr const char* const kRows[4] = {"blend_forward_rows_kernel<3>", "blend_forward_rows_kernel<6>",
+                                                       "blend_forward_rows_kernel<9>", "blend_forward_rows_kernel<12>"};
+        OGS_LAUNCH_NAMED(chan_name<C>(kRows), blend_forward_rows_kernel<C>, dim3(vtiles), dim3(kBlock), 0, s,
+                         (const uint2*)is.ranges, (const uint32_t*)is.qcount, (const float*)stream_base<C>(a.sorted_rec),
+                         (const uint32_t*)quad_base(a.quad_list), a.W, a.H, gx, tiles, a.bg, a.out_color, a.out_depth,
+                         a.out_alpha, is.n_contrib, is.final_T, blend_prefetch_lines(), order);
+        OGS_LAUNCH_CHECK(a.debug, s);
+        return OGS_OK;
+    }
     OGS_LAUNCH_NAMED(chan_name<C>(kNames), blend_forward_kernel<C>, dim3(vtiles), dim3(kBlock), 0, s,
                      (const uint2*)is.ranges, (const uint32_t*)is.qcount, (const float*)stream_base<C>(a.sorted_rec),
                      (const uint32_t*)quad_base(a.quad_list), a.W, a.H, gx, tiles, a.bg, a.out_color, a.out_depth,

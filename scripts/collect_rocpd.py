@@ -28,6 +28,27 @@ def short(name):
     return re.sub(r"<(\d+)[^>]*>", r"<\1>", m.group(1))          # blend_backward_kernel<9, 3, false, double> -> <9>
 
 
+# dominant read pattern of every kernel of the step (second field: is it the pattern the guide's x2 is calibrated for?)
+READ_PATTERN = {
+    "preprocess_kernel": ("coalesced vector loads of the per-Gaussian inputs (SH rows 192 B per lane as 16-byte loads)", True),
+    "preprocess_backward_kernel": ("coalesced 16-byte vector loads of inputs + the 128-byte fp64 gradient record", True),
+    "pack_sorted_kernel": ("4-byte point-list stream + 32 / 48-byte record gathers by sorted id (16-byte loads)", True),
+    "duplicate_kernel": ("4-byte / 16-byte coalesced loads of the depth-ordered per-Gaussian state", True),
+    "radix_hist_kernel": ("4-byte-per-lane coalesced key stream", False),
+    "radix_scatter_kernel": ("4-byte-per-lane coalesced key / value streams", False),
+    "radix_onesweep_kernel": ("4-byte-per-lane coalesced key / value streams + status-word polls", False),
+    "radix_hist_all_kernel": ("4-byte-per-lane coalesced key stream", False),
+    "radix_rowscan_kernel": ("small table, L2 resident", False),
+    "scan_reduce_kernel": ("4-byte-per-lane loads through a gather index", False),
+    "scan_apply_kernel": ("4-byte-per-lane loads through a gather index", False),
+    "tile_ranges_kernel": ("4-byte-per-lane coalesced key stream", False),
+    "tile_order_kernel": ("small table", False),
+    "blend_forward_kernel": ("SCALAR loads of the record stream (s_load_dwordx16) + one-dword-per-line vector prefetch touches", False),
+    "blend_backward_kernel": ("SCALAR loads of the record stream + line touches + per-pixel 4-byte loads; writes are fp64 atomics", False),
+    "blend_backward_feat_kernel": ("SCALAR loads of the record stream + line touches; writes are fp64 atomics", False),
+}
+
+
 def dbs(d):
     return glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
 
@@ -69,17 +90,26 @@ def main():
     rows = kernel_stats(os.path.join(d, "trace"), f"profiles/{tag}_kernel_stats.csv")
     fetch = counters([os.path.join(d, "fetch")])
     write = counters([os.path.join(d, "write")])
-    table, traffic = {}, {}
+    table, traffic, how = {}, {}, {}
     for k in sorted(set(fetch) | set(write)):
         fk, wk = fetch.get(k, {}).get("FETCH_SIZE", 0.0), write.get(k, {}).get("WRITE_SIZE", 0.0)
-        b = (2.0 * fk + wk) * 1024.0
+        # The guide's x2 on FETCH_SIZE is calibrated for wide (16 B per lane) coalesced streaming reads only.  Per kernel:
+        # which read pattern dominates, hence which figure is quoted; both bounds are always kept.
+        pattern, streaming = READ_PATTERN.get(k.split("<")[0], ("unclassified", False))
+        lo, hi = (fk + wk) * 1024.0, (2.0 * fk + wk) * 1024.0
+        b = hi
         table[k] = {"FETCH_SIZE_KiB_per_launch": fk, "WRITE_SIZE_KiB_per_launch": wk,
-                    "launches_sampled": fetch.get(k, {}).get("_launches", 0), "hbm_bytes_corrected_per_launch": b}
+                    "launches_sampled": fetch.get(k, {}).get("_launches", 0), "read_pattern": pattern,
+                    "fetch_correction": "x2 (calibrated: wide coalesced streaming reads)" if streaming else
+                                        "x2 quoted as an UPPER bound (uncalibrated pattern: the true figure lies between the two)",
+                    "hbm_bytes_lower_bound_per_launch": lo, "hbm_bytes_corrected_per_launch": b}
         traffic[k] = b
+        how[k] = table[k]["fetch_correction"] + " -- " + pattern
     json.dump(table, open(f"profiles/{tag}_pmc_fetch_write_per_launch.json", "w"), indent=1)
     src = f"scripts/profile_round.sh {tag}: rocprofv3 --pmc passes of '{cmd}' (S1M-1080p fused pass, 8 views cycled)"
     traffic["_ogs_version"] = ver
     traffic["_source"] = src + "; bytes = 2*FETCH_SIZE + WRITE_SIZE (KiB -> B), per launch"
+    traffic["_correction_per_kernel"] = how
     json.dump(traffic, open("profiles/pmc_traffic.json", "w"), indent=1)
     sq = counters([os.path.join(d, "sq1"), os.path.join(d, "sq2")])
     for k, cs in sq.items():

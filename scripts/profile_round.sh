@@ -5,12 +5,12 @@
 #   3. --pmc SQ_* passes                  VALU / SALU / SMEM instruction counts, wave cycles
 # and post-process them into profiles/ (tracked).  Usage: bash scripts/profile_round.sh r02
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT && mkdir -p $OUT profiles
-BENCH="python3 bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-kmeans --no-extras"
+BENCH="python3 bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-kmeans --no-extras --no-extra-workloads"
 echo "[profile] kernel trace"; rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- $BENCH > $OUT/trace.log 2>&1
 echo "[profile] FETCH_SIZE";   rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o f -- $BENCH > $OUT/fetch.log 2>&1
 echo "[profile] WRITE_SIZE";   rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o w -- $BENCH > $OUT/write.log 2>&1
