@@ -434,6 +434,279 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     pf.retire(reinterpret_cast<uint32_t*>(grad_rec), W);
 }
 
+// ---- full backward, one list per 4x4 pixel block (round 3) ----------------------------------------------------------
+// Same idea as blend_forward_rows_kernel (blend_fwd.hip): a wave owns a quadrant and walks the quadrant's index stream
+// back to front in CHUNKS of 32 entries; lane e gathers and parks record e in LDS, an exact 4x4-block reach test splits the
+// chunk into four lists, and the four DPP rows of the wave -- row r = the 16 pixels of block r -- walk their lists side by
+// side with every operand of the per-pixel arithmetic in VGPRs (the quadrant walk pays 4 issue cycles for almost every
+// instruction because the record sits in SGPRs, and keeps ~51 % of its lanes busy).
+// Reduction: a chunk is worked off in four WINDOWS of eight slots.  Inside a window every row walks ITS entries of those
+// eight slots (lockstep; a row that has fewer reads the dummy record) and leaves its blend weight w and its
+// q = opacity * G * dL/dalpha in the A tile of PairFold -- in the row of the SLOT, at the columns of its own 16 pixels.  Rows
+// never share a column, so after the window the tile holds, per slot, w and q over all 64 pixels of the quadrant (zero where
+// a block was not reached: the tile is cleared per window), and the window ends exactly like a batch of the quadrant
+// kernel: sixteen v_mfma_f32_16x16x4_f32 (K = 64 pixels), the moment shift, one atomic instruction per four slots.  Same
+// atomic traffic as the quadrant kernel (one record per (entry, quadrant)); the per-(pixel, entry) arithmetic is
+// blend_backward_kernel's, in the same order.  LDS per wave: tile 4.25 KB + parked records 1.5 KB + lists 0.5 KB.
+template <int NP4>
+struct RowsBwdLds {
+    static constexpr int kChunk = 32;
+    float t[16 * kPairStride];          // PairFold's A tile: row rw(e') (+2 for q), column = pixel of the quadrant
+    float4 rec[(kChunk + 1) * NP4];     // parked records (+ dummy slot kChunk)
+    uint32_t list[4][kChunk / 8][8];    // per row and window: chunk slots that can reach the block, padded with the dummy
+};
+
+template <int C, int GC, bool DEPTH, typename ACC>
+__global__ __launch_bounds__(kBlock) void blend_backward_rows_kernel(
+    const uint2* __restrict__ ranges, const float* __restrict__ stream, const uint32_t* __restrict__ quad_list, int W,
+    int H, int gx, int tiles, const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+    const uint32_t* __restrict__ qcount, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha_map,
+    ACC* __restrict__ grad_rec, int pf_lines, const uint32_t* __restrict__ tile_order) {
+    constexpr int NV4 = stream_vec4(C);
+    constexpr int RS = NV4 * 4;
+    constexpr int GS = grad_stride(C);
+    constexpr int NP4 = DEPTH ? NV4 : (8 + GC + 3) / 4;           // float4s of a record this loop touches
+    constexpr int kChunk = RowsBwdLds<NP4>::kChunk;
+    static_assert(C + 7 <= 16, "gradient record must fit 16 slots");
+    __shared__ RowsBwdLds<NP4> s_lds[kBlock / kWave];
+
+    const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
+    const int img = tile / tiles, timg = tile - img * tiles;
+    const int tx = timg % gx, ty = timg / gx;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row = lane >> 4, l16 = lane & 15;
+    const int qx0 = tx * kTile + (wave & 1) * 8, qy0 = ty * kTile + (wave >> 1) * 8;
+    const int bxq = 4 * (row & 1) + (l16 & 3), byq = 4 * (row >> 1) + (l16 >> 2);     // this lane's pixel inside the quadrant
+    const int px = qx0 + bxq, py = qy0 + byq;
+    const int qcol = byq * 8 + bxq;                                                    // its column of the A tile
+    const bool inside = px < W && py < H;
+    const float fx = (float)px, fy = (float)py;
+    const size_t plane = (size_t)W * H;
+    const size_t pix = (size_t)img * plane + (size_t)py * W + px;
+    dL_dcolor += (size_t)img * (C - 1) * plane;
+    const float* __restrict__ dcol_img = dL_dcolor + (size_t)img * plane;
+
+    const uint2 range = ranges[tile];
+    const int last_contrib = inside ? (int)n_contrib[pix] : 0;
+    const int hi = __builtin_amdgcn_readfirstlane(wave_max_i32(last_contrib));
+    if (hi == 0) return;
+    const int n_tile = (int)(range.y - range.x);
+    const float* __restrict__ tb = stream + (size_t)range.x * RS;
+    const uint32_t* __restrict__ qi = quad_list + ((size_t)range.x * 5 + (size_t)wave * n_tile);
+    const int n_kept = (int)qcount[tile * 5 + 4];
+    const uint32_t lim = n_kept > 0 ? (uint32_t)n_kept - 1u : 0u;
+    RecordPrefetch pf;
+    pf.issue(tb, n_kept, RS, tid, pf_lines & 0xFF);
+    const bool skip_atomics = (pf_lines & 0x300) != 0;
+
+    RowsBwdLds<NP4>& L = s_lds[wave];
+    const float T_final = inside ? final_T[pix] : 0.f;
+    float T = T_final;
+    float g[GC];
+    float bg_dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < GC; ++c) {
+        g[c] = inside ? dL_dcolor[c * plane + pix] : 0.f;
+        bg_dot += bg[c] * g[c];
+    }
+    const float gd = (DEPTH && inside) ? dL_ddepth[pix] : 0.f;
+    const float ga = (inside && dL_dalpha_map) ? dL_dalpha_map[pix] : 0.f;
+    float R[GC];
+#pragma unroll
+    for (int c = 0; c < GC; ++c) R[c] = 0.f;
+    float Rd = 0.f, Ra = 0.f;
+    const float tf_bg = T_final * bg_dot;
+    // B matrix of PairFold: lane (column n, group kq) feeds MFMA j with the quadrant pixel q = 16 (j >> 2) + 4 kq + (j & 3)
+    const int n = l16, kq = row;
+    float Bm[16];
+    const float* __restrict__ ddepth_img = DEPTH ? dL_ddepth + (size_t)img * plane : nullptr;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int q = 16 * (j >> 2) + 4 * kq + (j & 3);
+        const int ppx = qx0 + (q & 7), ppy = qy0 + (q >> 3);
+        const float u = (float)(q & 7) - 3.5f, v = (float)(q >> 3) - 3.5f;
+        const bool in = ppx < W && ppy < H;
+        const bool gcolumn = n < C || (DEPTH && n == kSlotDepth);
+        float b = 0.f;
+        if (in && gcolumn) b = (DEPTH && n == kSlotDepth) ? ddepth_img[(size_t)ppy * W + ppx] : dcol_img[(size_t)n * plane + (size_t)ppy * W + ppx];
+        b = n == kSlotMoments ? 1.f : b;
+        b = n == kSlotMoments + 1 ? u : b;
+        b = n == kSlotMoments + 2 ? v : b;
+        b = n == kSlotMoments + 3 ? u * u : b;
+        b = n == kSlotMoments + 4 ? u * v : b;
+        b = n == kSlotMoments + 5 ? v * v : b;
+        Bm[j] = b;
+    }
+    const float x0 = (float)qx0 + 3.5f, y0 = (float)qy0 + 3.5f;           // quadrant centre (moment origin)
+    const bool column_used = n < C || (DEPTH && n == kSlotDepth) || n >= kSlotMoments;
+    if (lane == 0) {                          // dummy record: h < 0 -> never a candidate
+#pragma unroll
+        for (int k = 0; k < NP4; ++k) L.rec[kChunk * NP4 + k] = float4{0.f, 0.f, 0.f, 0.f};
+        L.rec[kChunk * NP4 + 1] = float4{0.f, -1.f, 0.f, 0.f};
+    }
+
+    // one (pixel, entry): blend_backward_kernel's arithmetic; leaves w and q in the A-tile rows of window slot ew
+    auto consume = [&](const float4 (&rv)[NP4], int ew, int idx) {
+        auto at = [&](int i) { const float4 q4 = rv[i >> 2]; return (i & 3) == 0 ? q4.x : (i & 3) == 1 ? q4.y : (i & 3) == 2 ? q4.z : q4.w; };
+        const float dx = at(0) - fx, dy = at(1) - fy;
+        const float power = blend_power(at(2), at(3), at(4), dx, dy);
+        const float hh = at(5);
+        const bool near = fabsf(power + hh) <= hh, reached = idx < last_contrib;
+        const bool cand = near && reached;
+        const uint64_t cand_mask = __ballot(near) & __ballot(reached);
+        if (cand_mask == 0ull) return;
+        const float opac = at(6);
+        const float Graw = __expf(power);
+        const float alpha = fminf(0.99f, opac * Graw);
+        const bool act = cand && alpha >= kAlphaMin;
+        if ((__ballot(alpha >= kAlphaMin) & cand_mask) != 0ull) {
+            const float al = act ? alpha : 0.f;
+            const float G = act ? Graw : 0.f;
+            const float inv = __builtin_amdgcn_rcpf(1.0f - al);
+            T = T * inv;
+            const float w = al * T;
+            float dL_dalpha = 0.f;
+#pragma unroll
+            for (int c = 0; c < GC; ++c) {
+                const float diff = at(8 + c) - R[c];
+                dL_dalpha += diff * g[c];
+                R[c] += al * diff;
+            }
+            if constexpr (DEPTH) {
+                const float diff = at(8 + C) - Rd;
+                dL_dalpha += diff * gd;
+                Rd += al * diff;
+            }
+            {
+                const float diff = 1.0f - Ra;
+                dL_dalpha += diff * ga;
+                Ra += al * diff;
+            }
+            dL_dalpha = dL_dalpha * T - inv * tf_bg;
+            const float q = opac * (G * dL_dalpha);
+            // rows of window slot ew (PairFold's order: w in row 4 (ew / 2) + (ew % 2), q two rows below), this pixel's column.
+            // A dummy step (ew = 8) is no candidate anywhere: it never gets here with act, and its w = q = 0 go nowhere
+            if (act) {
+                float* cell = &L.t[(((ew >> 1) << 2) | (ew & 1)) * kPairStride + qcol];
+                cell[0] = w;
+                cell[2 * kPairStride] = q;
+            }
+        }
+    };
+
+    // back to front over the quadrant stream, kChunk positions at a time: chunk slot e <-> position top - e
+    for (int top = hi - 1; top >= 0; top -= kChunk) {
+        // ---- 1. gather + park (lanes 0..31); reach test: lane (e, half) tests blocks 2 half, 2 half + 1 ----
+        const int e = lane & (kChunk - 1), half = lane >> 5;
+        const int pos = top - e;
+        const bool have = pos >= 0;
+        const uint32_t ridx = have ? min(qi[pos], lim) : 0u;
+        const float4* __restrict__ rp = reinterpret_cast<const float4*>(tb + (size_t)ridx * RS);
+        float4 rg[NP4];
+#pragma unroll
+        for (int k = 0; k < NP4; ++k) rg[k] = rp[k];
+        if (half == 0) {
+#pragma unroll
+            for (int k = 0; k < NP4; ++k) L.rec[e * NP4 + k] = rg[k];
+        }
+        bool reach2[2];
+        {
+            const float gxp = rg[0].x, gyp = rg[0].y;
+            const float A = -2.f * rg[0].z, B = -rg[0].w, Cc = -2.f * rg[1].x, thr = -2.f * rg[1].y;
+            const float nbA = -B / A, nbC = -B / Cc;
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                const int b = 2 * half + bb;
+                const float ox = (float)(qx0 + 4 * (b & 1)), oy = (float)(qy0 + 4 * (b >> 1));
+                const float m = max_power_in_box(A, B, Cc, nbA, nbC, gxp - ox - 3.f, gxp - ox, gyp - oy - 3.f, gyp - oy);
+                reach2[bb] = have && m >= thr;
+            }
+        }
+        // ---- 2. per row and window: compacted slot lists, padded with the dummy ----
+        {
+            uint32_t* flat = &L.list[0][0][0];
+            flat[lane] = (uint32_t)kChunk;
+            flat[lane + kWave] = (uint32_t)kChunk;
+        }
+        uint32_t mask_b[4];
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+            const uint64_t m64 = __ballot(reach2[bb]);
+            mask_b[bb] = (uint32_t)m64;                 // block bb     (lanes of half 0)
+            mask_b[2 + bb] = (uint32_t)(m64 >> 32);     // block 2 + bb (lanes of half 1)
+            const uint32_t mine = half == 0 ? (uint32_t)m64 : (uint32_t)(m64 >> 32);
+            const uint32_t win = (mine >> (e & ~7)) & 0xFFu;                       // this slot's window
+            const int posw = __popc(win & ((1u << (e & 7)) - 1u));
+            if (reach2[bb]) L.list[2 * half + bb][e >> 3][posw] = (uint32_t)e;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- 3. four windows of eight slots ----
+#pragma unroll 1
+        for (int w = 0; w < kChunk / 8; ++w) {
+            const uint32_t any = ((mask_b[0] | mask_b[1] | mask_b[2] | mask_b[3]) >> (8 * w)) & 0xFFu;    // slots some block reaches
+            if (any == 0u) continue;
+            int nsteps = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) nsteps = max(nsteps, (int)__popc((mask_b[b] >> (8 * w)) & 0xFFu));
+            // clear the A tile (16 rows x 64 columns; the row stride leaves the pad columns alone)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int cell = (lane + k * kWave) * 4;                 // float4 cells 0..255 -> row = cell / 64, column = cell % 64
+                *reinterpret_cast<float4*>(&L.t[(cell >> 6) * kPairStride + (cell & 63)]) = float4{0.f, 0.f, 0.f, 0.f};
+            }
+            const uint32_t* __restrict__ mylist = L.list[row][w];
+            float4 ra[NP4], rb[NP4];
+            uint32_t e0 = mylist[0], e1 = mylist[1];
+#pragma unroll
+            for (int k = 0; k < NP4; ++k) ra[k] = L.rec[e0 * NP4 + k];
+            for (int t = 0; t < nsteps; t += 2) {
+                const uint32_t e2 = mylist[(t + 2) & 7], e3 = mylist[(t + 3) & 7];
+#pragma unroll
+                for (int k = 0; k < NP4; ++k) rb[k] = L.rec[e1 * NP4 + k];
+                consume(ra, (int)e0 - 8 * w, top - (int)e0);
+#pragma unroll
+                for (int k = 0; k < NP4; ++k) ra[k] = L.rec[e2 * NP4 + k];
+                if (t + 1 < nsteps) consume(rb, (int)e1 - 8 * w, top - (int)e1);
+                e0 = e2; e1 = e3;
+            }
+            // ---- window flush: PairFold::flush on the eight slots of the window ----
+            floatx4 d = {0.f, 0.f, 0.f, 0.f}, d1 = d;
+#pragma unroll
+            for (int J = 0; J < 4; ++J) {
+                const float4 a = *reinterpret_cast<const float4*>(&L.t[n * kPairStride + 16 * J + 4 * kq]);
+                d = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, Bm[4 * J], d, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, Bm[4 * J + 1], d1, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, Bm[4 * J + 2], d, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, Bm[4 * J + 3], d1, 0, 0, 0);
+            }
+            d = d + d1;
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int ew = 2 * kq + rr;                                   // window slot of this register pair
+                const int slot = 8 * w + ew;
+                const float4 gv = L.rec[slot * NP4], g2 = L.rec[slot * NP4 + 1];
+                const uint32_t gid = __float_as_uint(g2.w);
+                const float a = gv.x - x0, b = gv.y - y0;
+                const float own = d[2 + rr];
+                const float M0 = row_bcast<kSlotMoments>(own), Mu = row_bcast<kSlotMoments + 1>(own), Mv = row_bcast<kSlotMoments + 2>(own);
+                const float ta = a * M0, tbb = b * M0;
+                float val = own;                                                        // S0
+                val = n == kSlotMoments + 1 ? ta - own : val;                           // Sx
+                val = n == kSlotMoments + 2 ? tbb - own : val;                          // Sy
+                val = n == kSlotMoments + 3 ? own + a * (ta - 2.f * Mu) : val;          // Sxx
+                val = n == kSlotMoments + 4 ? (own + a * (tbb - Mv)) - b * Mu : val;    // Sxy
+                val = n == kSlotMoments + 5 ? own + b * (tbb - 2.f * Mv) : val;         // Syy
+                val = n < kSlotMoments ? d[rr] : val;                                   // feature / depth slots
+                if (((any >> ew) & 1u) != 0u && column_used && !skip_atomics) atomicAdd(grad_rec + ((size_t)gid * GS + n), (ACC)val);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    pf.retire(reinterpret_cast<uint32_t*>(grad_rec), W);
+}
+
 // Features-only backward (SURVEY.md section 0 item 6, section 8 f1 "skip geometry grads when detached"): from
 // stage 1 on every Gaussian parameter but `_ins_feat` is detached (train.py:431-436), so the only gradient the pass
 // owes is dL/dfeature_c = sum over pixels of (alpha * T) * dL/dpixel_c.  No alpha-gradient recursion, no geometry
@@ -531,6 +804,12 @@ __global__ void wave_fold16_test_kernel(const float* __restrict__ in, float* __r
     for (int k = 0; k < 16; ++k) v[k] = in[threadIdx.x * 16 + k];
     out[threadIdx.x] = wave_fold16(v);
 }
+// OGS_BLEND_ROWS_BWD=1: the per-4x4-block full backward (blend_backward_rows_kernel); default: the quadrant walk
+static bool backward_rows_enabled() {
+    static const bool v = [] { const char* e = getenv("OGS_BLEND_ROWS_BWD"); return e && atoi(e) != 0; }();
+    return v;
+}
+
 template <int C, typename ACC>
 int launch_c(const OgsRasterBwdArgs& a, const ImageState& is, void* grad_rec_, hipStream_t s) {
     ACC* grad_rec = static_cast<ACC*>(grad_rec_);
@@ -558,7 +837,16 @@ int launch_c(const OgsRasterBwdArgs& a, const ImageState& is, void* grad_rec_, h
         OGS_LAUNCH_CHECK(a.debug, s);
         return OGS_OK;
     }
+    static constexpr const char* const kRowNames[4] = {"blend_backward_rows_kernel<3>", "blend_backward_rows_kernel<6>",
+                                                       "blend_backward_rows_kernel<9>", "blend_backward_rows_kernel<12>"};
+    const bool rows = backward_rows_enabled();
 #define OGS_BWD_LAUNCH(GCV, DEPTHV)                                                                                  \
+    if (rows)                                                                                                        \
+        OGS_LAUNCH_NAMED(chan_name<C>(kRowNames), (blend_backward_rows_kernel<C, GCV, DEPTHV, ACC>), dim3(vtiles), dim3(kBlock), 0, s, \
+                     (const uint2*)is.ranges, stream, quads, a.W, a.H, gx, gx * gy, a.bg, (const float*)is.final_T,                  \
+                     (const uint32_t*)is.n_contrib, (const uint32_t*)is.qcount, a.dL_dcolor, a.dL_ddepth, a.dL_dalpha, grad_rec,  \
+                     blend_prefetch_lines(), order);                                                                 \
+    else                                                                                                             \
     OGS_LAUNCH_NAMED(chan_name<C>(kNames), (blend_backward_kernel<C, GCV, DEPTHV, ACC>), dim3(vtiles), dim3(kBlock), 0, s, \
                      (const uint2*)is.ranges, stream, quads, a.W, a.H, gx, gx * gy, a.bg, (const float*)is.final_T,                  \
                      (const uint32_t*)is.n_contrib, (const uint32_t*)is.qcount, a.dL_dcolor, a.dL_ddepth, a.dL_dalpha, grad_rec,  \

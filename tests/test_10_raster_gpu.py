@@ -2,6 +2,8 @@
 identical seeded inputs.  Tolerances (BASELINE.json north_star): images / depth / alpha within 1e-4 fp32;
 radii, tile ranges, sorted (tile<<32 | depth_bits) keys and point lists BIT-EXACT; n_contrib exact except
 for pixels where the device exp and the host exp disagree on a threshold (bounded fraction, documented)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -719,3 +721,19 @@ def test_random_configurations_forward_parity(gpu_device):
             helpers.assert_close_modulo_threshold_flips(depth.cpu().numpy(), ref["depth"], IMG_TOL * 10, flip_tol=4e-2)
         except AssertionError as e:
             raise AssertionError(f"{tag}: {e}") from None
+
+
+@pytest.mark.parametrize("env", [{"OGS_BLEND_ROWS": "0"}, {"OGS_BLEND_ROWS_BWD": "1"}])
+def test_alternative_blend_kernels_keep_parity(gpu_device, env):
+    """The blend kernels exist in two structures each: the quadrant walk (records in SGPRs) and the per-4x4-block walk
+    (records in VGPRs through LDS).  Defaults: forward = per-block, backward = quadrant (measured).  The
+    non-default ones are selected by environment variables read once per process, so they are checked in a child process:
+    forward / backward parity against the oracle, the adversarial scenes, the fused and grouped passes."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_10_raster_gpu.py"), "-x", "-q", "-m", "gpu", "-k",
+           "test_forward_parity or test_backward_parity or test_adversarial_scenes or test_fused_pass or test_grouped_pass or test_tiny_pass"]
+    r = subprocess.run(cmd, cwd=root, env=dict(os.environ, **env), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert " passed" in r.stdout and " failed" not in r.stdout
