@@ -44,6 +44,8 @@ READ_PATTERN = {
     "tile_ranges_kernel": ("4-byte-per-lane coalesced key stream", False),
     "tile_order_kernel": ("small table", False),
     "blend_forward_kernel": ("SCALAR loads of the record stream (s_load_dwordx16) + one-dword-per-line vector prefetch touches", False),
+    "blend_forward_rows_kernel": ("per-lane 16-byte gathers of 80-byte records (L2 resident after the line-touch prefetch) + the prefetch touches", False),
+    "blend_backward_rows_kernel": ("per-lane 16-byte gathers of records + per-pixel 4-byte loads; writes are fp64 atomics", False),
     "blend_backward_kernel": ("SCALAR loads of the record stream + line touches + per-pixel 4-byte loads; writes are fp64 atomics", False),
     "blend_backward_feat_kernel": ("SCALAR loads of the record stream + line touches; writes are fp64 atomics", False),
 }
@@ -129,7 +131,7 @@ def main():
     print("kernel stats (top 6):")
     for r in rows[:6]:
         print("  %-60s calls %4d avg %9.1f us" % ((short(r[0]) or r[0][:60]), r[1], r[3]))
-    for k in ("blend_backward_kernel<9>", "blend_forward_kernel<9>", "pack_sorted_kernel<9>"):
+    for k in ("blend_backward_kernel<9>", "blend_forward_rows_kernel<9>", "pack_sorted_kernel<9>"):
         print(k, "HBM MB/launch", round(traffic.get(k, 0) / 1e6, 1), {c: round(v) for c, v in sq.get(k, {}).items() if c.startswith("SQ_INSTS")})
 
 
