@@ -797,6 +797,93 @@ __global__ __launch_bounds__(kBlock) void blend_backward_feat_kernel(
     pf.retire(reinterpret_cast<uint32_t*>(grad_rec), W);
 }
 
+// ---- features-only backward, records through LDS instead of SGPRs (round 3 experiment) -----------------------------------
+// blend_backward_feat_kernel with ONE change: the wave-uniform record reaches the per-pixel arithmetic as VGPRs (a chunk of 64
+// records gathered by the lanes, parked in LDS, read back with broadcast ds_read_b128) instead of as SGPRs (scalar loads).  Same
+// quadrant walk, same lane occupancy, same fold -- but every vector instruction that read the record now issues at 2 cycles
+// instead of 4 (profiles/r03_valu_issue_price_list.json).
+template <int C, int F0, typename ACC>
+__global__ __launch_bounds__(kBlock) void blend_backward_feat_lds_kernel(
+    const uint2* __restrict__ ranges, const float* __restrict__ stream, const uint32_t* __restrict__ quad_list, int W,
+    int H, int gx, int tiles, const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ qcount,
+    const float* __restrict__ dL_dcolor, ACC* __restrict__ grad_rec, int pf_lines, const uint32_t* __restrict__ tile_order) {
+    constexpr int RS = stream_vec4(C) * 4;
+    constexpr int GS = grad_stride(C);
+    constexpr int NS = C - F0;
+    static_assert(NS >= 1 && NS <= 9, "feature slots");
+    __shared__ WaveFoldLds s_fold[kBlock / kWave];
+    __shared__ float4 s_rec[kBlock / kWave][(kWave + 2) * 2];
+
+    const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
+    const int img = tile / tiles, timg = tile - img * tiles;
+    const int tx = timg % gx, ty = timg / gx;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = tx * kTile + (wave & 1) * 8 + (lane & 7);
+    const int py = ty * kTile + (wave >> 1) * 8 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const float fx = (float)px, fy = (float)py;
+    const size_t plane = (size_t)W * H;
+    const size_t pix = (size_t)img * plane + (size_t)py * W + px;
+    dL_dcolor += (size_t)img * C * plane;
+
+    const uint2 range = ranges[tile];
+    const int last_contrib = inside ? (int)n_contrib[pix] : 0;
+    const int hi = __builtin_amdgcn_readfirstlane(wave_max_i32(last_contrib));
+    if (hi == 0) return;
+    const int n_tile = (int)(range.y - range.x);
+    const float* __restrict__ tb = stream + (size_t)range.x * RS;
+    const uint32_t* __restrict__ qi = quad_list + ((size_t)range.x * 5 + (size_t)wave * n_tile);
+    const int n_kept = (int)qcount[tile * 5 + 4];
+    const uint32_t lim = n_kept > 0 ? (uint32_t)n_kept - 1u : 0u;
+    RecordPrefetch pf;
+    pf.issue(tb, n_kept, RS, tid, pf_lines & 0xFF);
+
+    RankOneFold<NS, 0, GS, ACC, true> fold;
+    fold.skip_atomics = (pf_lines & 0x100) != 0;
+    fold.init(&s_fold[wave], lane, tx, ty, wave, W, H,
+              [&](int n, size_t p) { return dL_dcolor[(size_t)(F0 + n) * plane + p]; });
+    float T = 1.0f;
+    float4* __restrict__ recs = s_rec[wave];
+
+    auto consume = [&](const float4& r0, const float4& r1, int idx) {
+        const float dx = r0.x - fx, dy = r0.y - fy;
+        const float power = blend_power(r0.z, r0.w, r1.x, dx, dy);
+        const float hh = r1.y;
+        const bool near = fabsf(power + hh) <= hh, reached = idx < last_contrib;
+        const bool cand = near && reached;
+        const uint64_t cand_mask = __ballot(near) & __ballot(reached);
+        if (cand_mask == 0ull) return;
+        const float alpha = fminf(0.99f, r1.z * __expf(power));
+        const bool act = cand && alpha >= kAlphaMin;
+        if ((__ballot(alpha >= kAlphaMin) & cand_mask) != 0ull) {
+            const float al = act ? alpha : 0.f;
+            const float w = al * T;
+            T = T * (1.0f - al);
+            fold.push(w, (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(r1.w)), grad_rec, lane);
+        }
+    };
+    for (int c0 = 0; c0 < hi; c0 += kWave) {
+        const int cnt = min(kWave, hi - c0);
+        const uint32_t ridx = lane < cnt ? min(qi[c0 + lane], lim) : 0u;
+        const float4* __restrict__ rp = reinterpret_cast<const float4*>(tb + (size_t)ridx * RS);
+        const float4 g0 = rp[0], g1 = rp[1];
+        recs[lane * 2] = g0;
+        recs[lane * 2 + 1] = g1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float4 a0 = recs[0], a1 = recs[1];
+        for (int e = 0; e < cnt; e += 2) {
+            const float4 b0 = recs[(e + 1) * 2], b1 = recs[(e + 1) * 2 + 1];
+            consume(a0, a1, c0 + e);
+            a0 = recs[(e + 2) * 2]; a1 = recs[(e + 2) * 2 + 1];
+            if (e + 1 < cnt) consume(b0, b1, c0 + e + 1);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (fold.cnt > 0) fold.flush(grad_rec, lane);
+    pf.retire(reinterpret_cast<uint32_t*>(grad_rec), W);
+}
+
 // self-test hook for the 16-slot fold (wave_fold.h; used by mask_ops.hip): in [64 lanes][16 slots] -> out[lane] = value left in each lane
 __global__ void wave_fold16_test_kernel(const float* __restrict__ in, float* __restrict__ out) {
     float v[16];
@@ -804,6 +891,12 @@ __global__ void wave_fold16_test_kernel(const float* __restrict__ in, float* __r
     for (int k = 0; k < 16; ++k) v[k] = in[threadIdx.x * 16 + k];
     out[threadIdx.x] = wave_fold16(v);
 }
+// OGS_BLEND_FEAT_LDS=1: features-only backward with the records through LDS (VGPR operands) instead of scalar loads
+static bool feat_lds_enabled() {
+    static const bool v = [] { const char* e = getenv("OGS_BLEND_FEAT_LDS"); return e && atoi(e) != 0; }();
+    return v;
+}
+
 // OGS_BLEND_ROWS_BWD=1: the per-4x4-block full backward (blend_backward_rows_kernel); default: the quadrant walk
 static bool backward_rows_enabled() {
     static const bool v = [] { const char* e = getenv("OGS_BLEND_ROWS_BWD"); return e && atoi(e) != 0; }();
@@ -824,7 +917,15 @@ int launch_c(const OgsRasterBwdArgs& a, const ImageState& is, void* grad_rec_, h
     const uint32_t* order = tile_order_of(is, vtiles, a.P);     // the forward's heaviest-first order (blend_fwd.hip)
     if (backward_is_features_only(a)) {
         // only dL/dcolors_precomp is owed (stages >= 1, train.py:431-436): no alpha recursion, no geometry partials
+    static constexpr const char* const kFeatLdsNames[4] = {"blend_backward_feat_lds_kernel<3>", "blend_backward_feat_lds_kernel<6>",
+                                                           "blend_backward_feat_lds_kernel<9>", "blend_backward_feat_lds_kernel<12>"};
+    const bool feat_lds = feat_lds_enabled();
 #define OGS_BWD_FEAT(F0V)                                                                                             \
+    if (feat_lds)                                                                                                     \
+    OGS_LAUNCH_NAMED(chan_name<C>(kFeatLdsNames), (blend_backward_feat_lds_kernel<C, F0V, ACC>), dim3(vtiles), dim3(kBlock), 0, \
+                     s, (const uint2*)is.ranges, stream, quads, a.W, a.H, gx, gx * gy, (const uint32_t*)is.n_contrib,    \
+                     (const uint32_t*)is.qcount, a.dL_dcolor, grad_rec, blend_prefetch_lines(), order);                \
+    else                                                                                                              \
     OGS_LAUNCH_NAMED(chan_name<C>(kFeatNames), (blend_backward_feat_kernel<C, F0V, ACC>), dim3(vtiles), dim3(kBlock), 0, \
                      s, (const uint2*)is.ranges, stream, quads, a.W, a.H, gx, gx * gy, (const uint32_t*)is.n_contrib,    \
                      (const uint32_t*)is.qcount, a.dL_dcolor, grad_rec, blend_prefetch_lines(), order)
