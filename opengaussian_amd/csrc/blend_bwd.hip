@@ -797,11 +797,13 @@ __global__ __launch_bounds__(kBlock) void blend_backward_feat_kernel(
     pf.retire(reinterpret_cast<uint32_t*>(grad_rec), W);
 }
 
-// ---- features-only backward, records through LDS instead of SGPRs (round 3 experiment) -----------------------------------
+// ---- features-only backward, records through LDS instead of SGPRs (round 3; the default) --------------------------------
 // blend_backward_feat_kernel with ONE change: the wave-uniform record reaches the per-pixel arithmetic as VGPRs (a chunk of 64
 // records gathered by the lanes, parked in LDS, read back with broadcast ds_read_b128) instead of as SGPRs (scalar loads).  Same
 // quadrant walk, same lane occupancy, same fold -- but every vector instruction that read the record now issues at 2 cycles
-// instead of 4 (profiles/r03_valu_issue_price_list.json).
+// instead of 4 (profiles/r03_valu_issue_price_list.json): 0.449 -> 0.364 ms at the headline workload.  The same change on the
+// FULL backward (geometry + features through LDS, or geometry through LDS and features on the scalar path) measured 0.645 ->
+// 0.648 / 0.69 / 0.77 ms and was not kept: DESIGN.md section 3 item 9.
 template <int C, int F0, typename ACC>
 __global__ __launch_bounds__(kBlock) void blend_backward_feat_lds_kernel(
     const uint2* __restrict__ ranges, const float* __restrict__ stream, const uint32_t* __restrict__ quad_list, int W,
@@ -891,9 +893,9 @@ __global__ void wave_fold16_test_kernel(const float* __restrict__ in, float* __r
     for (int k = 0; k < 16; ++k) v[k] = in[threadIdx.x * 16 + k];
     out[threadIdx.x] = wave_fold16(v);
 }
-// OGS_BLEND_FEAT_LDS=1: features-only backward with the records through LDS (VGPR operands) instead of scalar loads
+// features-only backward: records through LDS (VGPR operands; default) or, OGS_BLEND_FEAT_LDS=0, through scalar loads
 static bool feat_lds_enabled() {
-    static const bool v = [] { const char* e = getenv("OGS_BLEND_FEAT_LDS"); return e && atoi(e) != 0; }();
+    static const bool v = [] { const char* e = getenv("OGS_BLEND_FEAT_LDS"); return !e || atoi(e) != 0; }();
     return v;
 }
 

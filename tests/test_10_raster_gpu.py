@@ -723,17 +723,19 @@ def test_random_configurations_forward_parity(gpu_device):
             raise AssertionError(f"{tag}: {e}") from None
 
 
-@pytest.mark.parametrize("env", [{"OGS_BLEND_ROWS": "0"}, {"OGS_BLEND_ROWS_BWD": "1"}])
+@pytest.mark.parametrize("env", [{"OGS_BLEND_ROWS": "0"}, {"OGS_BLEND_ROWS_BWD": "1"}, {"OGS_BLEND_FEAT_LDS": "0"}])
 def test_alternative_blend_kernels_keep_parity(gpu_device, env):
     """The blend kernels exist in two structures each: the quadrant walk (records in SGPRs) and the per-4x4-block walk
-    (records in VGPRs through LDS).  Defaults: forward = per-block, backward = quadrant (measured).  The
+    (records in VGPRs through LDS).  Defaults: forward = per-block, backward = quadrant (measured); the
+    features-only backward walks quadrants with its records through LDS by default, through scalar loads otherwise.  The
     non-default ones are selected by environment variables read once per process, so they are checked in a child process:
     forward / backward parity against the oracle, the adversarial scenes, the fused and grouped passes."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_10_raster_gpu.py"), "-x", "-q", "-m", "gpu", "-k",
-           "test_forward_parity or test_backward_parity or test_adversarial_scenes or test_fused_pass or test_grouped_pass or test_tiny_pass"]
+           "test_forward_parity or test_backward_parity or test_adversarial_scenes or test_fused_pass or test_grouped_pass or test_tiny_pass"
+           " or test_features_only_backward"]
     r = subprocess.run(cmd, cwd=root, env=dict(os.environ, **env), capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:]
     assert " passed" in r.stdout and " failed" not in r.stdout
