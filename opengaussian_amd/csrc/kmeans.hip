@@ -555,37 +555,45 @@ __global__ __launch_bounds__(kBlock) void kmeans_gemm_pass_kernel(const float* _
     for (int cb = 0; cb < CB; ++cb) acc[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
     const int64_t nblk = (N + kBlock - 1) / kBlock;
     // Rows travel HBM -> registers -> LDS, one trip AHEAD: the loads of trip t+1 are issued before the tiles of trip t are
-    // scored and land in LDS after the barrier that ends trip t, so their latency hides under the MFMA / argmax work.
-    // Three named float4 registers (576 = 2 x 256 + 64 float4s per trip at d = 9; an indexed array went to scratch).
-    constexpr int NV4 = kBlock * DT / 4;
-    static_assert(NV4 > 2 * kBlock - 1 ? NV4 <= 3 * kBlock : true, "three float4 per thread cover a trip");
+    // scored and land in LDS at the top of trip t+1, so their latency hides under the MFMA / argmax work.
+    // Three named float4 registers (144 = 2 x 64 + 16 float4s per wave and trip at d = 9; an indexed array went to scratch).
+    // Every wave stages, scores and accumulates ITS OWN 64 rows (a wave-private slice of `rows` / `ids_s`): nothing in the loop
+    // crosses waves, so the trips need no workgroup barrier -- LDS operations of one wave execute in order -- and the four
+    // waves of a workgroup drift apart freely (three __syncthreads per trip before: the kernel sat at 4 waves per SIMD, 128
+    // VGPRs, and every barrier parked three of them behind the slowest).
+    constexpr int WV4 = kWave * DT / 4;                                // float4 per wave and trip: 144 (d = 9) / 96 (d = 6)
+    static_assert(WV4 > kWave && WV4 <= 3 * kWave, "two or three float4 per lane cover a wave's rows");
+    float* wrows = rows + wave * kWave * DT;
     float4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0, q2 = q0;
     auto fast_trip = [&](int64_t b) {
         return b < nblk && (b + 1) * kBlock <= N && (reinterpret_cast<uintptr_t>(feat + b * kBlock * d) & 15u) == 0;
     };
     auto issue_loads = [&](int64_t b) {
-        const float4* s4 = reinterpret_cast<const float4*>(feat + b * kBlock * d);
-        q0 = s4[tid];
-        if (tid + kBlock < NV4) q1 = s4[tid + kBlock];
-        if (NV4 > 2 * kBlock && tid + 2 * kBlock < NV4) q2 = s4[tid + 2 * kBlock];
+        const float4* s4 = reinterpret_cast<const float4*>(feat + (b * kBlock + wave * kWave) * d);
+        q0 = s4[lane];
+        if (lane + kWave < WV4) q1 = s4[lane + kWave];
+        if (WV4 > 2 * kWave && lane + 2 * kWave < WV4) q2 = s4[lane + 2 * kWave];
     };
     bool prefetched = fast_trip(blockIdx.x);
     if (prefetched) issue_loads(blockIdx.x);
     for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
         const int64_t row0 = blk * kBlock;
         const int nrows = (int)min((int64_t)kBlock, N - row0);
-        const float* src = feat + row0 * d;
+        __builtin_amdgcn_wave_barrier();                               // the previous trip's reads of this wave's slice are issued
         if (prefetched) {
-            float4* r4 = reinterpret_cast<float4*>(rows);
-            r4[tid] = q0;
-            if (tid + kBlock < NV4) r4[tid + kBlock] = q1;
-            if (NV4 > 2 * kBlock && tid + 2 * kBlock < NV4) r4[tid + 2 * kBlock] = q2;
+            float4* r4 = reinterpret_cast<float4*>(wrows);
+            r4[lane] = q0;
+            if (lane + kWave < WV4) r4[lane + kWave] = q1;
+            if (WV4 > 2 * kWave && lane + 2 * kWave < WV4) r4[lane + 2 * kWave] = q2;
         } else {
-            for (int i = tid; i < kBlock * d; i += kBlock) rows[i] = i < nrows * d ? src[i] : 0.f;
+            const int wn = max(0, min(kWave, nrows - wave * kWave)) * d;        // floats of this wave's rows that exist
+            const float* src = feat + (row0 + wave * kWave) * d;
+            for (int i = lane; i < kWave * d; i += kWave) wrows[i] = i < wn ? src[i] : 0.f;
         }
         prefetched = fast_trip(blk + gridDim.x);
         if (prefetched) issue_loads(blk + gridDim.x);
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         // ---- scores + argmax: this wave's 64 points, 16 per tile; lane (j, g) works on point 16 t + j ----
 #pragma unroll 1
         for (int t = 0; t < 4; ++t) {
@@ -636,7 +644,8 @@ __global__ __launch_bounds__(kBlock) void kmeans_gemm_pass_kernel(const float* _
             }
         }
         if (ACCUM) {
-            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                           // this wave's ids are in LDS
             // one_hot(ids)^T @ rows on the bf16 path (as kmeans_accum_bf16_kernel: 32 points per MFMA group, three exact
             // bf16 terms per row value), with cheaper operand construction: the row values are split by truncation
             // (and / subtract, full-rate) and packed with v_perm; the one-hot factor of two points is ONE packed 16-bit
@@ -675,9 +684,9 @@ __global__ __launch_bounds__(kBlock) void kmeans_gemm_pass_kernel(const float* _
                 }
             }
         }
-        __syncthreads();
     }
     if (ACCUM) {
+        __syncthreads();                                               // wtab aliases every wave's rows
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll

@@ -1,9 +1,9 @@
-# SQ counters of the blend kernels under a given environment: bash scripts/prof_sq.sh TAG [VAR=VALUE ...]
+# SQ counters of the blend (PROF_RE=kmeans: k-means) kernels under a given environment: bash scripts/prof_sq.sh TAG [VAR=VALUE ...]
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 TAG=$1; shift
 for kv in "$@"; do export "$kv"; done
-B="python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-kmeans --no-extra-workloads"
+B="python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extra-workloads ${PROF_BENCH_FLAGS---no-kmeans}"
 rm -rf gpurun_out/sq_$TAG; mkdir -p gpurun_out/sq_$TAG
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_INSTS_SMEM -d gpurun_out/sq_$TAG/a -o s -- $B > gpurun_out/sq_$TAG/a.log 2>&1 &&
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS -d gpurun_out/sq_$TAG/b -o s -- $B > gpurun_out/sq_$TAG/b.log 2>&1 &&
@@ -21,9 +21,10 @@ for d in "abc":
         except Exception as e:
             print(d, e); continue
         for _, kn, cn, val in rows:
-            if "blend_" in kn:
-                import re
-                k = re.search(r"blend_\w+(<\d+)?", kn).group(0)
+            import re, os
+            m = re.search(os.environ.get("PROF_RE", "blend_") + r"\w+(<\w+)?", kn)
+            if m:
+                k = m.group(0)
                 acc[k][cn][0] += val; acc[k][cn][1] += 1
         for k, cs in acc.items():
             for c, v in cs.items():
