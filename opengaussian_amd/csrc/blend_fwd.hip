@@ -43,25 +43,27 @@ __device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d) {
 //   [8..8+C) features  [8+C] view depth, rest zero padding to a multiple of 4 floats.
 // The depth sits right behind the features so that the (feature, feature) / (feature, depth) operand pairs of
 // the blend loops' packed FMAs are even-aligned SGPR pairs straight out of s_load (no s_mov shuffles).
+// shared memory of the pack phase: carved out of one raw buffer so that the fused pack + blend kernel can reuse it
 template <int C>
-__global__ __launch_bounds__(kBlock) void pack_sorted_kernel(const uint2* __restrict__ ranges,
-                                                             const uint32_t* __restrict__ point_list, int gx,
-                                                             int tiles, const float4* __restrict__ rec,
-                                                             float4* __restrict__ stream,
-                                                             uint32_t* __restrict__ quad_list,
-                                                             uint32_t* __restrict__ qcount,
-                                                             const uint32_t* __restrict__ tile_order) {
+struct PackLds {
+    uint64_t wave_tot[kBlock / kWave];
+    float4 s_rec[kBlock * stream_vec4(C)];
+};
+
+// one tile: running[0..3] = entries kept per quadrant, running[4] = records kept by the tile (block-uniform on return)
+template <int C>
+__device__ __forceinline__ void pack_tile(const uint2 range, const uint32_t* __restrict__ point_list, int gx, int timg,
+                                          const float4* __restrict__ rec, float4* __restrict__ stream,
+                                          uint32_t* __restrict__ quad_list, PackLds<C>& lds, uint32_t (&running)[5]) {
     constexpr int NV = rec_vec4(C);
     constexpr int SV = stream_vec4(C);
-    __shared__ uint64_t wave_tot[kBlock / kWave];
-    __shared__ float4 s_rec[kBlock * SV];
-    const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;   // virtual tile: image (group) * tiles + tile in the image
-    const int timg = tile % tiles;
+    uint64_t* wave_tot = lds.wave_tot;
+    float4* s_rec = lds.s_rec;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
     const float X0 = (float)((timg % gx) * kTile), Y0 = (float)((timg / gx) * kTile);
-    uint32_t running[5] = {0u, 0u, 0u, 0u, 0u};            // kept entries so far: per quadrant, and by the tile (block-uniform)
+#pragma unroll
+    for (int q = 0; q < 5; ++q) running[q] = 0u;           // kept entries so far: per quadrant, and by the tile (block-uniform)
 
     for (int base = 0; base < n; base += kBlock) {
         const int i = base + tid;
@@ -156,7 +158,21 @@ __global__ __launch_bounds__(kBlock) void pack_sorted_kernel(const uint2* __rest
         for (int q = 0; q < 5; ++q) running[q] += (uint32_t)(total >> (12 * q)) & 0xFFFu;
         __syncthreads();
     }
-    if (tid == 0) {
+}
+
+template <int C>
+__global__ __launch_bounds__(kBlock) void pack_sorted_kernel(const uint2* __restrict__ ranges,
+                                                             const uint32_t* __restrict__ point_list, int gx,
+                                                             int tiles, const float4* __restrict__ rec,
+                                                             float4* __restrict__ stream,
+                                                             uint32_t* __restrict__ quad_list,
+                                                             uint32_t* __restrict__ qcount,
+                                                             const uint32_t* __restrict__ tile_order) {
+    __shared__ PackLds<C> lds;
+    const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;   // virtual tile: image (group) * tiles + tile in the image
+    uint32_t running[5];
+    pack_tile<C>(ranges[tile], point_list, gx, tile % tiles, rec, stream, quad_list, lds, running);
+    if (threadIdx.x == 0) {
 #pragma unroll
         for (int q = 0; q < 5; ++q) qcount[tile * 5 + q] = running[q];
     }
@@ -306,20 +322,26 @@ struct RowRec {          // one record in VGPRs
     __device__ __forceinline__ float feat(int c) const { return at(8 + c); }
 };
 
+constexpr int kRowSlots = 65;                // 64 chunk entries + the dummy that a finished row keeps reading
+constexpr int kRowListLen = 72;              // 64 + slack for the two-ahead index reads
 template <int C>
-__global__ __launch_bounds__(kBlock) void blend_forward_rows_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ qcount, const float* __restrict__ stream,
-    const uint32_t* __restrict__ quad_list, int W, int H, int gx, int tiles, const float* __restrict__ bg, float* __restrict__ out_color,
+struct RowsLds {
+    float4 s_rec[kBlock / kWave][kRowSlots * stream_vec4(C)];
+    uint32_t s_list[kBlock / kWave][4][kRowListLen];
+};
+
+// one tile; n = this wave's quadrant count, n_kept = records kept by the tile (qcount[tile * 5 + wave / 4])
+template <int C>
+__device__ __forceinline__ void blend_rows_tile(
+    const uint2 range, int n, int n_kept, const float* __restrict__ stream,
+    const uint32_t* __restrict__ quad_list, int W, int H, int gx, int img, int timg, const float* __restrict__ bg, float* __restrict__ out_color,
     float* __restrict__ out_depth, float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib,
-    float* __restrict__ final_T, int pf_lines, const uint32_t* __restrict__ tile_order) {
+    float* __restrict__ final_T, int pf_lines, RowsLds<C>& lds) {
     constexpr int NV4 = stream_vec4(C);
     constexpr int RS = NV4 * 4;                  // floats per stream record
-    constexpr int kSlots = 65;                   // 64 chunk entries + the dummy that a finished row keeps reading
-    constexpr int kListLen = 72;                 // 64 + slack for the two-ahead index reads
-    __shared__ float4 s_rec[kBlock / kWave][kSlots * NV4];
-    __shared__ uint32_t s_list[kBlock / kWave][4][kListLen];
-    const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
-    const int img = tile / tiles, timg = tile - img * tiles;
+    constexpr int kListLen = kRowListLen;
+    auto& s_rec = lds.s_rec;
+    auto& s_list = lds.s_list;
     const int tx = timg % gx, ty = timg / gx;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row = lane >> 4, l16 = lane & 15;
@@ -329,10 +351,7 @@ __global__ __launch_bounds__(kBlock) void blend_forward_rows_kernel(
     const bool inside = px < W && py < H;
     const float fy = (float)py;
 
-    const uint2 range = ranges[tile];
     const int n_tile = (int)(range.y - range.x);
-    const int n = (int)qcount[tile * 5 + wave];
-    const int n_kept = (int)qcount[tile * 5 + 4];
     const float* __restrict__ tb = stream + (size_t)range.x * RS;
     const uint32_t* __restrict__ qi = quad_list + ((size_t)range.x * 5 + (size_t)wave * n_tile);
     const uint32_t lim = n_kept > 0 ? (uint32_t)n_kept - 1u : 0u;
@@ -451,6 +470,50 @@ __global__ __launch_bounds__(kBlock) void blend_forward_rows_kernel(
         final_T[pix] = T;
     }
     pf.retire(n_contrib, W);
+}
+
+template <int C>
+__global__ __launch_bounds__(kBlock) void blend_forward_rows_kernel(
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ qcount, const float* __restrict__ stream,
+    const uint32_t* __restrict__ quad_list, int W, int H, int gx, int tiles, const float* __restrict__ bg, float* __restrict__ out_color,
+    float* __restrict__ out_depth, float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib,
+    float* __restrict__ final_T, int pf_lines, const uint32_t* __restrict__ tile_order) {
+    __shared__ RowsLds<C> lds;
+    const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
+    const int img = tile / tiles, timg = tile - img * tiles;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    blend_rows_tile<C>(ranges[tile], (int)qcount[tile * 5 + wave], (int)qcount[tile * 5 + 4], stream, quad_list, W, H, gx, img, timg, bg,
+                       out_color, out_depth, out_alpha, n_contrib, final_T, pf_lines, lds);
+}
+
+// ---- pack + forward blend of a tile in ONE workgroup (round 3) -------------------------------------------------------
+// pack_sorted_kernel is bound by the latency of its gathers (61 % of the HBM peak, little arithmetic), the blend by vector
+// issue: run back to back they leave the other resource idle in turn.  Here a workgroup packs ITS tile -- same code, same
+// global outputs (the backward reads the compacted records, the quadrant streams and the counts) -- and blends it right
+// away from the records it just wrote (its own CU's L2 / L1: __syncthreads orders them at workgroup scope), so that on every
+// CU some workgroups gather while others blend.  One launch less, and the counts travel in registers.
+template <int C>
+__global__ __launch_bounds__(kBlock) void pack_blend_forward_kernel(
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
+    float4* __restrict__ stream, uint32_t* __restrict__ quad_list, uint32_t* __restrict__ qcount, int W, int H, int gx, int tiles,
+    const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha,
+    uint32_t* __restrict__ n_contrib, float* __restrict__ final_T, const uint32_t* __restrict__ tile_order) {
+    constexpr size_t kBytes = sizeof(PackLds<C>) > sizeof(RowsLds<C>) ? sizeof(PackLds<C>) : sizeof(RowsLds<C>);
+    __shared__ __attribute__((aligned(16))) unsigned char raw[kBytes];
+    const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
+    const int img = tile / tiles, timg = tile - img * tiles;
+    const uint2 range = ranges[tile];
+    uint32_t running[5];
+    pack_tile<C>(range, point_list, gx, timg, rec, stream, quad_list, *reinterpret_cast<PackLds<C>*>(raw), running);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) qcount[tile * 5 + q] = running[q];
+    }
+    __syncthreads();        // the tile's records and index streams are written (workgroup-scope release / acquire); LDS changes hands
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int n = (int)(wave == 0 ? running[0] : wave == 1 ? running[1] : wave == 2 ? running[2] : running[3]);
+    blend_rows_tile<C>(range, n, (int)running[4], reinterpret_cast<const float*>(stream), quad_list, W, H, gx, img, timg, bg, out_color,
+                       out_depth, out_alpha, n_contrib, final_T, 0, *reinterpret_cast<RowsLds<C>*>(raw));
 }
 
 // test/diagnostic export: translate the per-quadrant stream index kept in n_contrib back to the reference's
@@ -711,12 +774,28 @@ static bool blend_rows_enabled() {
     return v;
 }
 
+// pack and forward blend of a tile in one workgroup (pack_blend_forward_kernel); OGS_PACK_FUSED=0: two launches
+static bool pack_fused_enabled() {
+    static const bool v = [] { const char* e = getenv("OGS_PACK_FUSED"); return !(e && atoi(e) == 0); }();
+    return v;
+}
+
 template <int C>
 int launch_c(const OgsRasterFwdArgs& a, const GeomState& gs, const ImageState& is, int64_t D, hipStream_t s) {
     const int gx = (a.W + kTile - 1) / kTile, gy = (a.H + kTile - 1) / kTile;
     const int tiles = gx * gy;
     const unsigned vtiles = (unsigned)tiles * (unsigned)num_groups_of(a.num_groups);
     const uint32_t* order = D > 0 ? launch_tile_order(is, vtiles, a.P, s, a.debug) : nullptr;
+    if (D > 0 && blend_rows_enabled() && pack_fused_enabled()) {
+        static constexpr const char* const kFused[4] = {"pack_blend_forward_kernel<3>", "pack_blend_forward_kernel<6>",
+                                                        "pack_blend_forward_kernel<9>", "pack_blend_forward_kernel<12>"};
+        OGS_LAUNCH_NAMED(chan_name<C>(kFused), pack_blend_forward_kernel<C>, dim3(vtiles), dim3(kBlock), 0, s,
+                         (const uint2*)is.ranges, (const uint32_t*)a.point_list, (const float4*)gs.rec, stream_base<C>(a.sorted_rec),
+                         quad_base(a.quad_list), is.qcount, a.W, a.H, gx, tiles, a.bg, a.out_color, a.out_depth, a.out_alpha,
+                         is.n_contrib, is.final_T, order);
+        OGS_LAUNCH_CHECK(a.debug, s);
+        return OGS_OK;
+    }
     if (D > 0) {
         static constexpr const char* const kPack[4] = {"pack_sorted_kernel<3>", "pack_sorted_kernel<6>",
                                                        "pack_sorted_kernel<9>", "pack_sorted_kernel<12>"};

@@ -1,4 +1,4 @@
-# timing experiments on the backward blend (results are wrong with OGS_BLEND_PREFETCH bits >= 8 set): bash scripts/bwd_ab.sh
+# A/B runs of bench.py under different environments on one box: edit the `run` lines
 cd $GRAFT_REPO_ROOT
 run() {  # name, env...
   name=$1; shift
@@ -6,9 +6,9 @@ run() {  # name, env...
   python - $name <<'PY'
 import json, sys
 d = json.load(open(f"gpurun_out/ab_{sys.argv[1]}.json"))
-k = {a: round(b, 4) for a, b in d["kernels_ms_per_step"].items() if "blend_b" in a}
-print(sys.argv[1], round(d["ms_per_step"], 4), k)
+k = {a: round(b, 4) for a, b in d["kernels_ms_per_step"].items() if "blend_f" in a or "pack" in a}
+print(sys.argv[1], round(d["ms_per_step"], 4), k, "stage1", round(d["stage1_pass"]["ms_per_step"], 4))
 PY
 }
-OGS_BLEND_BWD_VREC=2 timeout -k 10 600 python -m pytest tests/test_10_raster_gpu.py tests/test_11_render_gpu.py -x -q -m gpu 2>&1 | tail -3 && \
-run quad && run vrec32 OGS_BLEND_BWD_VREC=2 && run vrec64 OGS_BLEND_BWD_VREC=1
+timeout -k 10 600 python -m pytest tests/test_10_raster_gpu.py tests/test_11_render_gpu.py -x -q -m gpu 2>&1 | tail -3 && \
+run fused && run split OGS_PACK_FUSED=0 && run fused2 && run split2 OGS_PACK_FUSED=0

@@ -723,11 +723,13 @@ def test_random_configurations_forward_parity(gpu_device):
             raise AssertionError(f"{tag}: {e}") from None
 
 
-@pytest.mark.parametrize("env", [{"OGS_BLEND_ROWS": "0"}, {"OGS_BLEND_ROWS_BWD": "1"}, {"OGS_BLEND_FEAT_LDS": "0"}])
+@pytest.mark.parametrize("env", [{"OGS_BLEND_ROWS": "0"}, {"OGS_BLEND_ROWS_BWD": "1"}, {"OGS_BLEND_FEAT_LDS": "0"},
+                                 {"OGS_PACK_FUSED": "0"}])
 def test_alternative_blend_kernels_keep_parity(gpu_device, env):
     """The blend kernels exist in two structures each: the quadrant walk (records in SGPRs) and the per-4x4-block walk
     (records in VGPRs through LDS).  Defaults: forward = per-block, backward = quadrant (measured); the
-    features-only backward walks quadrants with its records through LDS by default, through scalar loads otherwise.  The
+    features-only backward walks quadrants with its records through LDS by default, through scalar loads otherwise; pack and
+    forward blend of a tile run in one workgroup by default, as two launches otherwise.  The
     non-default ones are selected by environment variables read once per process, so they are checked in a child process:
     forward / backward parity against the oracle, the adversarial scenes, the fused and grouped passes."""
     import subprocess
