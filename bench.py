@@ -96,6 +96,9 @@ def algorithmic_bytes(P, D, npx, C, K_in, S=6):
     b["preprocess_kernel"] = P * (44 + 4 * K_in + 52)
     b["binning"] = D * (12 + 24 * S + 8)
     b["blend_forward_kernel"] = D * (28 + 4 * C + 4) + npx * (4 * C + 12)
+    # the fused pack + blend kernel does what the reference's forward blend does per list entry (gather the Gaussian's
+    # data, blend it): same algorithmic bytes; the stand-alone per-block blend kernel likewise
+    b["pack_blend_forward_kernel"] = b["blend_forward_rows_kernel"] = b["blend_forward_kernel"]
     b["blend_backward_kernel"] = npx * (4 * C + 16) + D * (28 + 4 * C + 4) + D * 2 * (4 * C + 28)
     b["preprocess_backward_kernel"] = P * (44 + 4 * K_in + 4 + 4 * C + 28) + P * (40 + 4 * K_in)
     b["fwd"] = b["preprocess_kernel"] + b["binning"] + b["blend_forward_kernel"]
