@@ -93,6 +93,12 @@ typedef struct OgsRasterFwdArgs {
      * (radius 0).  num_groups <= 1 (and group_ids == NULL): the plain single-image pass. */
     const int32_t* group_ids;    /* [P] or NULL */
     int32_t num_groups;          /* 0 or 1: ungrouped */
+    int32_t full_binning;        /* 0 (default): the (Gaussian, tile) pairs that cannot reach alpha >= 1/255 on any pixel of their
+                                  * tile are dropped before the tile sort -- point_list, the tile ranges and what
+                                  * ogs_raster_export_binning returns hold the reachable pairs only, in the reference's order
+                                  * (images and gradients do not change: those pairs contribute nothing).  != 0: the reference's
+                                  * full list (every tile of every footprint rectangle), the unreachable pairs flagged in bit 31
+                                  * of point_list.  (Occupies what used to be tail padding: the struct size is unchanged.) */
 } OgsRasterFwdArgs;
 
 /* Arguments of the backward pass.  Mirrors upstream rasterize_gaussians_backward(bg, means3D,

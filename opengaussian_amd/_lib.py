@@ -27,6 +27,7 @@ class OgsRasterFwdArgs(C.Structure):
         ("out_color", _vp), ("out_depth", _vp), ("out_alpha", _vp), ("radii", _vp),
         ("geom_buffer", _vp), ("geom_tmp", _vp), ("image_buffer", _vp), ("point_list", _vp),
         ("binning_tmp", _vp), ("sorted_rec", _vp), ("quad_list", _vp), ("group_ids", _vp), ("num_groups", C.c_int32),
+        ("full_binning", C.c_int32),
     ]
 
 

@@ -135,7 +135,7 @@ constexpr int kFlatScanBlocks = 16384;   // up to 33.5 M elements scan in two la
 template <int ITEMS>
 __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const uint32_t* __restrict__ keys, int64_t n_cap,
                                                             const uint32_t* __restrict__ n_dev, int shift,
-                                                            int bits, uint32_t* __restrict__ hist, int nblocks) {
+                                                            int bits, uint32_t* __restrict__ hist, int nblocks, bool drop) {
     __shared__ uint32_t h[256];
     const int64_t n = n_dev ? min((int64_t)*n_dev, n_cap) : n_cap;
     const int ndig = 1 << bits;
@@ -146,7 +146,10 @@ __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const uint32_t* __re
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const int64_t idx = base + i * kBlock + threadIdx.x;
-        if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & mask], 1u);
+        if (idx < n) {
+            const uint32_t k = keys[idx];
+            if (!(drop && k == kDropKey)) atomicAdd(&h[(k >> shift) & mask], 1u);
+        }
     }
     __syncthreads();
     if ((int)threadIdx.x < ndig) hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint32_t* _
                                                                const uint32_t* __restrict__ n_dev, int shift,
                                                                int bits, const uint32_t* __restrict__ offsets,
                                                                const uint32_t* __restrict__ row_total,
-                                                               int nblocks) {
+                                                               int nblocks, bool drop, uint32_t* __restrict__ kept_out) {
     __shared__ uint32_t wave_hist_s[kBlock / kWave][256];
     __shared__ uint32_t scan_sums[4];
     __shared__ uint32_t dig_start[256], glob_base[256];
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint32_t* _
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const int64_t idx = base + i * kWave + lane;
-        const bool valid = idx < n;
+        const bool valid = drop ? key[i] != kDropKey : idx < n;       // (slots past n were loaded as kDropKey)
         const uint32_t d = (key[i] >> shift) & mask;
         uint64_t peers = __ballot(valid);
         for (int b = 0; b < bits; ++b) {
@@ -254,6 +257,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint32_t* _
     // ... and its global start: sum of the totals of all smaller digits + this digit's prefix over workgroups
     uint32_t dummy_total;
     const uint32_t digit_base = block_exclusive_scan(tid < ndig ? row_total[tid] : 0u, dummy_total, scan_sums);
+    if (kept_out != nullptr && blockIdx.x == 0 && tid == 0) *kept_out = dummy_total;     // keys that survive this pass (drop)
     if (tid < ndig) {
         dig_start[tid] = local_start;
         glob_base[tid] = digit_base + offsets[(size_t)tid * nblocks + blockIdx.x] - local_start;
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint32_t* _
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const int64_t idx = base + i * kWave + lane;
-        if (idx < n) {
+        if (drop ? key[i] != kDropKey : idx < n) {
             const uint32_t d = (key[i] >> shift) & mask;
             const uint32_t lp = dig_start[d] + wave_hist_s[wave][d] + rank[i];
             stage_k[lp] = key[i];
@@ -303,7 +307,7 @@ struct RadixPlanDev { int npass; int shift[4]; int bits[4]; };
 
 __global__ __launch_bounds__(kBlock) void radix_hist_all_kernel(const uint32_t* __restrict__ keys, int64_t n_cap,
                                                                 const uint32_t* __restrict__ n_dev, RadixPlanDev plan,
-                                                                uint32_t* __restrict__ ghist /*[4][256]*/) {
+                                                                uint32_t* __restrict__ ghist /*[4][256]*/, bool drop) {
     __shared__ uint32_t h[4][256];
     const int64_t n = n_dev ? min((int64_t)*n_dev, n_cap) : n_cap;
 #pragma unroll
@@ -311,6 +315,7 @@ __global__ __launch_bounds__(kBlock) void radix_hist_all_kernel(const uint32_t* 
     __syncthreads();
     for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * kBlock) {
         const uint32_t k = keys[idx];
+        if (drop && k == kDropKey) continue;              // dropped by the first pass: in none of the histograms
 #pragma unroll
         for (int p = 0; p < 4; ++p)
             if (p < plan.npass) atomicAdd(&h[p][(k >> plan.shift[p]) & ((1u << plan.bits[p]) - 1u)], 1u);
@@ -330,7 +335,8 @@ __global__ __launch_bounds__(kBlock) void radix_onesweep_kernel(const uint32_t* 
                                                                 const uint32_t* __restrict__ ghist /*[256], this pass*/,
                                                                 uint32_t* __restrict__ status /*[tiles][256], zeroed*/,
                                                                 uint32_t* __restrict__ ticket /*zeroed*/,
-                                                                uint32_t* __restrict__ err) {
+                                                                uint32_t* __restrict__ err, bool drop,
+                                                                uint32_t* __restrict__ kept_out) {
     __shared__ uint32_t wave_hist_s[kBlock / kWave][256];
     __shared__ uint32_t scan_sums[4];
     __shared__ uint32_t dig_start[256], glob_base[256];
@@ -361,7 +367,7 @@ __global__ __launch_bounds__(kBlock) void radix_onesweep_kernel(const uint32_t* 
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const int64_t idx = base + i * kWave + lane;
-        const bool valid = idx < n;
+        const bool valid = drop ? key[i] != kDropKey : idx < n;       // (slots past n were loaded as kDropKey)
         const uint32_t d = (key[i] >> shift) & mask;
         uint64_t peers = __ballot(valid);
         for (int b = 0; b < bits; ++b) {
@@ -395,6 +401,7 @@ __global__ __launch_bounds__(kBlock) void radix_onesweep_kernel(const uint32_t* 
     const uint32_t local_start = block_exclusive_scan(run_len, n_valid, scan_sums);
     uint32_t dummy_total;
     const uint32_t digit_base = block_exclusive_scan(tid < ndig ? ghist[tid] : 0u, dummy_total, scan_sums);
+    if (kept_out != nullptr && tile == 0 && tid == 0) *kept_out = dummy_total;             // keys that survive this pass (drop)
     // decoupled look-back: keys with digit `tid` in the tiles before this one.  kLookBack status words are fetched at once
     // (independent loads in flight together: a poll is a ~1 us round trip to the memory side, and with every tile of a
     // P-sized sort resident at the same time a tile walks back over MANY counts before it meets an inclusive one).
@@ -436,7 +443,7 @@ __global__ __launch_bounds__(kBlock) void radix_onesweep_kernel(const uint32_t* 
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const int64_t idx = base + i * kWave + lane;
-        if (idx < n) {
+        if (drop ? key[i] != kDropKey : idx < n) {
             const uint32_t d = (key[i] >> shift) & mask;
             const uint32_t lp = dig_start[d] + wave_hist_s[wave][d] + rank[i];
             stage_k[lp] = key[i];
@@ -556,7 +563,7 @@ struct SweepTmp {
 
 // Start of a sort of `npass` digit passes over the SAME multiset of keys: zero the scratch, histogram every digit.
 int radix_sort_begin(const uint32_t* keys, int64_t n, const uint32_t* n_dev, int npass, const int* shifts, const int* bits,
-                     void* tmp, hipStream_t stream, int debug) {
+                     void* tmp, hipStream_t stream, int debug, bool drop) {
     if (n <= 0) return OGS_OK;
     if (npass < 1 || npass > 4) { set_error("radix_sort_begin: npass=%d out of range", npass); return OGS_ERR_INVALID_ARG; }
     const SweepTmp t = SweepTmp::carve(tmp, n, npass);
@@ -570,24 +577,25 @@ int radix_sort_begin(const uint32_t* keys, int64_t n, const uint32_t* n_dev, int
     }
     const int64_t want = (n + kBlock * 16 - 1) / (kBlock * 16);
     const int grid = (int)(want < 1 ? 1 : (want > kHistAllBlocks ? kHistAllBlocks : want));
-    OGS_LAUNCH(radix_hist_all_kernel, dim3(grid), dim3(kBlock), 0, stream, keys, n, n_dev, plan, t.ghist);
+    OGS_LAUNCH(radix_hist_all_kernel, dim3(grid), dim3(kBlock), 0, stream, keys, n, n_dev, plan, t.ghist, drop);
     OGS_LAUNCH_CHECK(debug, stream);
     return OGS_OK;
 }
 
 // Pass `pass` (0-based, as planned in radix_sort_begin) of the sort: ONE launch.
 int radix_sort_pass(int pass, int npass, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
-                    int64_t n, int shift, int bits, void* tmp, hipStream_t stream, int debug, const uint32_t* n_dev) {
+                    int64_t n, int shift, int bits, void* tmp, hipStream_t stream, int debug, const uint32_t* n_dev, bool drop,
+                    uint32_t* kept_out) {
     if (n <= 0) return OGS_OK;
     const SweepTmp t = SweepTmp::carve(tmp, n, npass);
     const int items = sweep_items_for(n);
     const int nb = (int)((n + (int64_t)kBlock * items - 1) / ((int64_t)kBlock * items));
     if (items == 4) {
         OGS_LAUNCH(radix_onesweep_kernel<4>, dim3(nb), dim3(kBlock), 0, stream, keys_in, vals_in, keys_out, vals_out, n, n_dev,
-                   shift, bits, (const uint32_t*)(t.ghist + pass * 256), t.status[pass], t.ticket + pass, t.err);
+                   shift, bits, (const uint32_t*)(t.ghist + pass * 256), t.status[pass], t.ticket + pass, t.err, drop, kept_out);
     } else {
         OGS_LAUNCH(radix_onesweep_kernel<16>, dim3(nb), dim3(kBlock), 0, stream, keys_in, vals_in, keys_out, vals_out, n, n_dev,
-                   shift, bits, (const uint32_t*)(t.ghist + pass * 256), t.status[pass], t.ticket + pass, t.err);
+                   shift, bits, (const uint32_t*)(t.ghist + pass * 256), t.status[pass], t.ticket + pass, t.err, drop, kept_out);
     }
     OGS_LAUNCH_CHECK(debug, stream);
     return OGS_OK;
@@ -633,7 +641,8 @@ int exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out
 // n is the element count, or -- when n_dev != nullptr -- the CAPACITY the launch is sized for while the true
 // count (<= capacity after clamping) is read from device memory by the kernels.
 int radix_pass(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, int64_t n,
-               int shift, int bits, void* tmp, hipStream_t stream, int debug, const uint32_t* n_dev) {
+               int shift, int bits, void* tmp, hipStream_t stream, int debug, const uint32_t* n_dev, bool drop,
+               uint32_t* kept_out) {
     if (n <= 0) return OGS_OK;
     if (bits < 1 || bits > 8) { set_error("radix_pass: bits=%d out of range", bits); return OGS_ERR_INVALID_ARG; }
     const int items = sort_items_for(n);
@@ -642,19 +651,19 @@ int radix_pass(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_
     uint32_t* hist = static_cast<uint32_t*>(tmp);
     uint32_t* row_total = reinterpret_cast<uint32_t*>(static_cast<char*>(tmp) + align_up((size_t)256 * nb * sizeof(uint32_t)));
     if (items == 4) {
-        OGS_LAUNCH(radix_hist_kernel<4>, dim3(nb), dim3(kBlock), 0, stream, keys_in, n, n_dev, shift, bits, hist, nb);
+        OGS_LAUNCH(radix_hist_kernel<4>, dim3(nb), dim3(kBlock), 0, stream, keys_in, n, n_dev, shift, bits, hist, nb, drop);
     } else {
-        OGS_LAUNCH(radix_hist_kernel<16>, dim3(nb), dim3(kBlock), 0, stream, keys_in, n, n_dev, shift, bits, hist, nb);
+        OGS_LAUNCH(radix_hist_kernel<16>, dim3(nb), dim3(kBlock), 0, stream, keys_in, n, n_dev, shift, bits, hist, nb, drop);
     }
     OGS_LAUNCH_CHECK(debug, stream);
     OGS_LAUNCH(radix_rowscan_kernel, dim3(ndig), dim3(kBlock), 0, stream, hist, nb, row_total);
     OGS_LAUNCH_CHECK(debug, stream);
     if (items == 4) {
         OGS_LAUNCH(radix_scatter_kernel<4>, dim3(nb), dim3(kBlock), 0, stream, keys_in, vals_in, keys_out, vals_out, n, n_dev,
-                   shift, bits, (const uint32_t*)hist, (const uint32_t*)row_total, nb);
+                   shift, bits, (const uint32_t*)hist, (const uint32_t*)row_total, nb, drop, kept_out);
     } else {
         OGS_LAUNCH(radix_scatter_kernel<16>, dim3(nb), dim3(kBlock), 0, stream, keys_in, vals_in, keys_out, vals_out, n, n_dev,
-                   shift, bits, (const uint32_t*)hist, (const uint32_t*)row_total, nb);
+                   shift, bits, (const uint32_t*)hist, (const uint32_t*)row_total, nb, drop, kept_out);
     }
     OGS_LAUNCH_CHECK(debug, stream);
     return OGS_OK;

@@ -120,7 +120,7 @@ using namespace ogs;
 
 extern "C" {
 
-int ogs_version(void) { return 300; }
+int ogs_version(void) { return 301; }
 
 /* Per-kernel timing with HIP events recorded on the launch stream (bench.py's `roofline` leg).
  * ogs_prof_enable(1) starts a fresh recording; ogs_prof_collect() waits for the recorded events and
@@ -259,7 +259,13 @@ static int render_impl(const OgsRasterFwdArgs* a, int64_t D, bool deferred, hipS
         vbuf[passes & 1] = a->point_list;        // buffer index after `passes` flips from 0
         vbuf[(passes & 1) ^ 1] = bt.vals;
         const uint32_t* n_dev = deferred ? gt.num_rendered : nullptr;
-        rc = launch_duplicate(*a, gs, gt, bt.tile_keys[0], vbuf[0], (uint32_t)D, s);
+        // The (Gaussian, tile) pairs that cannot reach a pixel of their tile (52 % on the bench scene) leave the list in the FIRST
+        // pass of the tile sort: duplicate gives them the key kDropKey, the pass leaves those out of its histograms and of its
+        // output and reports how many keys it wrote; every later pass, the tile ranges and pack see the reachable pairs only,
+        // in the order the full list has them.  args.full_binning != 0 keeps the reference's full list (the dropped pairs stay,
+        // flagged in bit 31 of the value, and pack skips them): what ogs_raster_export_binning hands to the parity tests.
+        const bool cull = a->full_binning == 0;
+        rc = launch_duplicate(*a, gs, gt, bt.tile_keys[0], vbuf[0], (uint32_t)D, cull, s);
         if (rc != OGS_OK) return rc;
         const bool sweep = radix_onesweep_enabled(D);
         int shifts[4], nbits[4];
@@ -268,16 +274,19 @@ static int render_impl(const OgsRasterFwdArgs* a, int64_t D, bool deferred, hipS
             nbits[p] = (p == passes - 1) ? (bits == 0 ? 1 : bits - shifts[p]) : per;
         }
         if (sweep) {
-            rc = radix_sort_begin(bt.tile_keys[0], D, n_dev, passes, shifts, nbits, bt.sort_tmp, s, a->debug);
+            rc = radix_sort_begin(bt.tile_keys[0], D, n_dev, passes, shifts, nbits, bt.sort_tmp, s, a->debug, cull);
             if (rc != OGS_OK) return rc;
         }
         for (int p = 0; p < passes; ++p) {
             const int in = p & 1, out = in ^ 1;
-            rc = sweep ? radix_sort_pass(p, passes, bt.tile_keys[in], vbuf[in], bt.tile_keys[out], vbuf[out], D, shifts[p], nbits[p], bt.sort_tmp, s, a->debug, n_dev)
-                       : radix_pass(bt.tile_keys[in], vbuf[in], bt.tile_keys[out], vbuf[out], D, shifts[p], nbits[p], bt.sort_tmp, s, a->debug, n_dev);
+            const bool drop = cull && p == 0;
+            // launches stay sized for D (the host does not know the kept count); workgroups past it find nothing to do
+            const uint32_t* n_pass = (cull && p > 0) ? bt.kept : n_dev;
+            rc = sweep ? radix_sort_pass(p, passes, bt.tile_keys[in], vbuf[in], bt.tile_keys[out], vbuf[out], D, shifts[p], nbits[p], bt.sort_tmp, s, a->debug, n_pass, drop, drop ? bt.kept : nullptr)
+                       : radix_pass(bt.tile_keys[in], vbuf[in], bt.tile_keys[out], vbuf[out], D, shifts[p], nbits[p], bt.sort_tmp, s, a->debug, n_pass, drop, drop ? bt.kept : nullptr);
             if (rc != OGS_OK) return rc;
         }
-        rc = launch_tile_ranges(bt.tile_keys[passes & 1], D, is.ranges, tiles, s, a->debug, n_dev);
+        rc = launch_tile_ranges(bt.tile_keys[passes & 1], D, is.ranges, tiles, s, a->debug, cull ? bt.kept : n_dev);
         if (rc != OGS_OK) return rc;
     } else {
         OGS_HIP_CHECK(hipMemsetAsync(is.ranges, 0, (size_t)tiles * sizeof(uint2), s));

@@ -214,16 +214,20 @@ int exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out
 // One-launch-per-pass variant (decoupled look-back): radix_sort_begin zeroes the scratch and histograms every digit of
 // the `npass` planned passes in one read of the keys; radix_sort_pass is pass `pass` of that plan (ONE launch).
 // radix_onesweep_enabled(n): false for n >= 2^30 or OGS_RADIX=legacy (then use radix_pass, three launches per pass).
+// drop = true: keys equal to kDropKey are not part of the sort -- they are left out of the histograms and of the output of the
+// pass, which comes out COMPACTED; kept_out (device, optional) receives the number of keys the pass wrote, the element count of
+// every later pass.  (The tile sort drops the (Gaussian, tile) pairs that cannot reach a pixel of their tile: duplicate_kernel.)
+constexpr uint32_t kDropKey = 0xFFFFFFFFu;
 bool radix_onesweep_enabled(int64_t n);
 int radix_sort_begin(const uint32_t* keys, int64_t n, const uint32_t* n_dev, int npass, const int* shifts, const int* bits,
-                     void* tmp, hipStream_t stream, int debug);
+                     void* tmp, hipStream_t stream, int debug, bool drop = false);
 int radix_sort_pass(int pass, int npass, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
                     uint32_t* vals_out, int64_t n, int shift, int bits, void* tmp, hipStream_t stream, int debug,
-                    const uint32_t* n_dev = nullptr);
+                    const uint32_t* n_dev = nullptr, bool drop = false, uint32_t* kept_out = nullptr);
 // One stable LSD pass on bits [shift, shift+bits) of keys_in (bits <= 8): histogram table, row scan, scatter.
 int radix_pass(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
                int64_t n, int shift, int bits, void* tmp, hipStream_t stream, int debug,
-               const uint32_t* n_dev = nullptr);
+               const uint32_t* n_dev = nullptr, bool drop = false, uint32_t* kept_out = nullptr);
 
 struct GeomTmp {        // transient, but must survive from forward_geometry to forward_render
     uint32_t* tiles_touched;   // [P]
@@ -257,6 +261,7 @@ struct GeomTmp {        // transient, but must survive from forward_geometry to 
 struct BinTmp {         // transient, render phase
     uint32_t* tile_keys[2];    // [D]
     uint32_t* vals;            // [D] ping buffer (the pong is args->point_list)
+    uint32_t* kept;            // [1] pairs left after the first pass of the tile sort dropped the unreachable ones
     void* sort_tmp;
     static BinTmp carve(void* p, int64_t D) {
         Carver c(p);
@@ -264,12 +269,14 @@ struct BinTmp {         // transient, render phase
         b.tile_keys[0] = c.take<uint32_t>(D);
         b.tile_keys[1] = c.take<uint32_t>(D);
         b.vals = c.take<uint32_t>(D);
+        b.kept = c.take<uint32_t>(1);
         b.sort_tmp = c.take<char>(sort_tmp_bytes(D));
         return b;
     }
     static size_t bytes(int64_t D) {
         Carver c(nullptr);
         for (int i = 0; i < 3; ++i) c.take<uint32_t>(D);
+        c.take<uint32_t>(1);
         c.take<char>(sort_tmp_bytes(D));
         return c.off;
     }
@@ -281,7 +288,7 @@ int launch_tiny_geometry(const OgsRasterFwdArgs& a, const GeomState& gs, uint32_
 int launch_small_geometry(const OgsRasterFwdArgs& a, const GeomState& gs, const GeomTmp& gt, hipStream_t s);
 int launch_tiny_blend(const OgsRasterFwdArgs& a, const GeomState& gs, const uint32_t* order, hipStream_t s);
 int launch_duplicate(const OgsRasterFwdArgs& a, const GeomState& gs, const GeomTmp& gt, uint32_t* tile_keys,
-                     uint32_t* vals, uint32_t capacity, hipStream_t s);
+                     uint32_t* vals, uint32_t capacity, bool drop_unreachable, hipStream_t s);
 int launch_tile_ranges(const uint32_t* tile_keys_sorted, int64_t D, uint2* ranges, int64_t tiles, hipStream_t s,
                        int debug, const uint32_t* n_dev = nullptr);
 inline int num_groups_of(int g) { return g > 1 ? g : 1; }

@@ -369,7 +369,10 @@ __global__ __launch_bounds__(kBlock) void duplicate_kernel(int P, int W, int H, 
                                                            const uint32_t* __restrict__ offsets,
                                                            uint32_t* __restrict__ tile_keys,
                                                            uint32_t* __restrict__ vals, uint32_t capacity,
-                                                           const int32_t* __restrict__ group_ids) {
+                                                           const int32_t* __restrict__ group_ids, bool drop_unreachable) {
+    // drop_unreachable: a pair that cannot reach a pixel of its tile gets the key kDropKey, which the first pass of the tile
+    // sort leaves out (binning.hip) -- the sorted list then holds the reachable pairs only.  Otherwise the pair keeps its tile
+    // key and only its reach flag (bit 31 of the value) tells pack to skip it: the reference's full list (args.full_binning).
     // group_ids != nullptr (grouped pass): the key is the VIRTUAL tile group * tiles + tile
     // capacity: size of tile_keys / vals.  In the deferred render phase it is a cached estimate and the true
     // num_rendered may exceed it: such entries are dropped here and the host re-runs the phase (rasterizer.py).
@@ -463,14 +466,16 @@ __global__ __launch_bounds__(kBlock) void duplicate_kernel(int P, int W, int H, 
         const uint32_t o = first + j;
         if (o < capacity) {
             const uint32_t tx = (rc & 0xFFFu) + col, ty = (rc >> 12 & 0xFFFu) + row;
-            tile_keys[o] = s_key0[lo] + ty * (uint32_t)gx + tx;
+            const uint32_t key = s_key0[lo] + ty * (uint32_t)gx + tx;
             // can the Gaussian reach ANY pixel of this tile?  One box test per pair, here, while its geometry sits in
             // LDS: pack_sorted_kernel then gathers records (and tests the four quadrants) only for the pairs that can
             const float4 c = s_ctr[lo];
             const float4 k = s_con[lo];
             const float X0 = (float)(tx * kTile), Y0 = (float)(ty * kTile);
             const float m = max_power_in_box(k.x, c.w, k.y, k.z, k.w, c.x - X0 - 15.f, c.x - X0, c.y - Y0 - 15.f, c.y - Y0);
-            vals[o] = g | ((m >= c.z ? 1u : 0u) << kReachBit);
+            const bool reach = m >= c.z;
+            tile_keys[o] = (drop_unreachable && !reach) ? kDropKey : key;
+            vals[o] = g | ((reach ? 1u : 0u) << kReachBit);
         }
     }
 }
@@ -556,7 +561,7 @@ int launch_preprocess(const OgsRasterFwdArgs& a, const GeomState& gs, const Geom
 }
 
 int launch_duplicate(const OgsRasterFwdArgs& a, const GeomState& gs, const GeomTmp& gt, uint32_t* tile_keys,
-                     uint32_t* vals, uint32_t capacity, hipStream_t s) {
+                     uint32_t* vals, uint32_t capacity, bool drop_unreachable, hipStream_t s) {
     const int grid = (a.P + kBlock - 1) / kBlock;
     const int32_t* grp = a.num_groups > 1 ? a.group_ids : nullptr;
     if ((a.W + kTile - 1) / kTile > 4095 || (a.H + kTile - 1) / kTile > 4095) {
@@ -564,9 +569,9 @@ int launch_duplicate(const OgsRasterFwdArgs& a, const GeomState& gs, const GeomT
         return OGS_ERR_UNSUPPORTED;
     }
     switch (rec_vec4(a.C)) {
-        case 3: OGS_LAUNCH(duplicate_kernel<3>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals, capacity, grp); break;
-        case 4: OGS_LAUNCH(duplicate_kernel<4>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals, capacity, grp); break;
-        case 5: OGS_LAUNCH(duplicate_kernel<5>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals, capacity, grp); break;
+        case 3: OGS_LAUNCH(duplicate_kernel<3>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals, capacity, grp, drop_unreachable); break;
+        case 4: OGS_LAUNCH(duplicate_kernel<4>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals, capacity, grp, drop_unreachable); break;
+        case 5: OGS_LAUNCH(duplicate_kernel<5>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals, capacity, grp, drop_unreachable); break;
         default: set_error("unsupported record size"); return OGS_ERR_UNSUPPORTED;
     }
     OGS_LAUNCH_CHECK(a.debug, s);

@@ -15,6 +15,7 @@ channels; one pass then bins/sorts once and blends all channels (``color`` is [C
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import NamedTuple, Optional
 
 import torch
@@ -147,6 +148,26 @@ def _require_gpu(t: torch.Tensor, name: str):
         raise RuntimeError(f"{name} must live on the GPU (got {t.device}); the MI355X rasterizer has no CPU path")
 
 
+# Binning mode of the passes issued from this process (OgsRasterFwdArgs.full_binning, include/ogs_raster.h).  False (default): the
+# (Gaussian, tile) pairs that cannot reach a pixel of their tile leave the list in the first pass of the tile sort.  True: the
+# reference's full list is kept -- what tests/helpers.py::hip_export_binning compares with the oracle's binning entry by entry.
+FULL_BINNING = os.environ.get("OGS_FULL_BINNING", "0") == "1"      # the environment variable is for A-B timing runs
+
+
+class full_binning:
+    """Context manager: passes issued inside keep the reference's full (Gaussian, tile) list (diagnostics / parity tests)."""
+
+    def __enter__(self):
+        global FULL_BINNING
+        self._prev, FULL_BINNING = FULL_BINNING, True
+        return self
+
+    def __exit__(self, *exc):
+        global FULL_BINNING
+        FULL_BINNING = self._prev
+        return False
+
+
 def _fwd_args(rs, P, Cn, m3, shs, cols, opac, scl, rot, cov, bg, view, proj, campos, color, depth, alpha, radii, group_ids, G):
     a = OgsRasterFwdArgs()
     a.P, a.W, a.H, a.C = P, int(rs.image_width), int(rs.image_height), Cn
@@ -159,6 +180,7 @@ def _fwd_args(rs, P, Cn, m3, shs, cols, opac, scl, rot, cov, bg, view, proj, cam
     a.viewmatrix, a.projmatrix, a.campos = ptr(view), ptr(proj), ptr(campos)
     a.out_color, a.out_depth, a.out_alpha, a.radii = ptr(color), ptr(depth), ptr(alpha), ptr(radii)
     a.group_ids, a.num_groups = ptr(group_ids), G
+    a.full_binning = int(FULL_BINNING)
     return a
 
 
@@ -281,6 +303,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         radii = alloc(P, dtype=torch.int32, device=dev)
         ctx.raster_settings = rs
         ctx.P, ctx.Cn, ctx.num_rendered, ctx.tiny = P, Cn, 0, False
+        ctx.full_binning = bool(FULL_BINNING)
         if P == 0:
             # reference behaviour: zero images, nothing launched (SURVEY.md section 8(b) "Errors")
             ctx.save_for_backward()

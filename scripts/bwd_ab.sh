@@ -6,9 +6,8 @@ run() {  # name, env...
   python - $name <<'PY'
 import json, sys
 d = json.load(open(f"gpurun_out/ab_{sys.argv[1]}.json"))
-k = {a: round(b, 4) for a, b in d["kernels_ms_per_step"].items() if "blend_f" in a or "pack" in a}
-print(sys.argv[1], round(d["ms_per_step"], 4), k, "stage1", round(d["stage1_pass"]["ms_per_step"], 4))
+k = {a: round(b, 4) for a, b in d["kernels_ms_per_step"].items()}
+print(sys.argv[1], round(d["ms_per_step"], 4), "stage1", round(d["stage1_pass"]["ms_per_step"], 4), k)
 PY
 }
-timeout -k 10 600 python -m pytest tests/test_10_raster_gpu.py tests/test_11_render_gpu.py -x -q -m gpu 2>&1 | tail -3 && \
-run fused && run split OGS_PACK_FUSED=0 && run fused2 && run split2 OGS_PACK_FUSED=0
+run cull && run full OGS_FULL_BINNING=1 && run cull2 && run full2 OGS_FULL_BINNING=1

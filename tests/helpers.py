@@ -77,34 +77,85 @@ def _hip_forward(inp, cam, bg, sh_degree, device, requires_grad, debug):
     return out, leaves
 
 
-def hip_export_binning(color_tensor):
-    """Fetch sorted keys / ranges / n_contrib of the forward pass that produced `color_tensor`."""
+def _export_binning_of(a, D, point_list, W, H, dev):
+    """keys / ranges / n_contrib / raw point list of one pass through ogs_raster_export_binning; the lists are cut at the last
+    tile range's end (the default mode drops the unreachable pairs, so its lists are shorter than num_rendered)."""
     from opengaussian_amd import _lib
+    from opengaussian_amd._lib import ptr
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    keys = torch.zeros(max(D, 1), dtype=torch.int64, device=dev)
+    ranges = torch.zeros(gx * gy, 2, dtype=torch.int32, device=dev)
+    ncontrib = torch.zeros(H, W, dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().ogs_raster_export_binning(C.byref(a), D, ptr(keys), ptr(ranges), ptr(ncontrib),
+                                                    torch.cuda.current_stream().cuda_stream), "export_binning")
+    torch.cuda.synchronize()
+    ranges = ranges.cpu().numpy().view(np.uint32)
+    n = int(ranges[:, 1].max()) if ranges.size else 0
+    return (keys[:n].cpu().numpy().view(np.uint64), ranges, ncontrib.cpu().numpy().view(np.uint32),
+            point_list[:n].cpu().numpy().view(np.uint32))
+
+
+def hip_export_binning(color_tensor):
+    """Sorted keys / ranges / n_contrib / point list of the pass that produced `color_tensor`, in the REFERENCE's form: the full
+    (Gaussian, tile) list.  The rasterizer's default mode drops the pairs that cannot reach a pixel of their tile before the tile
+    sort, so for a pass issued in that mode this helper (a) exports the culled binning the pass really used, (b) re-renders the
+    saved inputs with `rasterizer.full_binning()` and exports the full binning, and (c) holds the two against each other:
+      * the culled (key, Gaussian) list == the full list filtered by the device's reach flag, entry by entry, same order;
+      * the culled tile ranges == the ranges of that filtered list;
+      * colour and alpha of the two passes are BIT-identical, and the culled pass' n_contrib maps onto the full pass' one
+        (same last contributor for every pixel);
+    then returns the full binning, which the callers compare with the oracle's (and whose dropped pairs they check in float64:
+    assert_reach_flags_keep_every_contributor)."""
+    from opengaussian_amd import _lib
+    from opengaussian_amd import rasterizer as R
     from opengaussian_amd._lib import OgsRasterFwdArgs, ptr
-    fn = color_tensor.grad_fn
-    ctx = fn
+    ctx = color_tensor.grad_fn
     (m3, shs, cols, opac, scl, rot, cov, bg, view, proj, campos, radii, alpha, geom, image,
      point_list, sorted_rec, quad_list) = ctx.saved_tensors
     rs = ctx.raster_settings
     D = ctx.num_rendered
     W, H = int(rs.image_width), int(rs.image_height)
     dev = m3.device
-    gx, gy = (W + 15) // 16, (H + 15) // 16
-    keys = torch.zeros(max(D, 1), dtype=torch.int64, device=dev)
-    ranges = torch.zeros(gx * gy, 2, dtype=torch.int32, device=dev)
-    ncontrib = torch.zeros(H, W, dtype=torch.int32, device=dev)
     a = OgsRasterFwdArgs()
     a.P, a.W, a.H, a.C = ctx.P, W, H, ctx.Cn
     a.geom_buffer, a.image_buffer, a.point_list = ptr(geom), ptr(image), ptr(point_list)
     a.sorted_rec, a.quad_list = ptr(sorted_rec), ptr(quad_list)
-    _lib.check(_lib.lib().ogs_raster_export_binning(C.byref(a), D, ptr(keys), ptr(ranges), ptr(ncontrib),
-                                                    torch.cuda.current_stream().cuda_stream), "export_binning")
-    torch.cuda.synchronize()
+    keys, ranges, ncontrib, raw = _export_binning_of(a, D, point_list, W, H, dev)
+    if not getattr(ctx, "full_binning", False):
+        assert ctx.num_groups == 1, "helper: grouped passes are exported in full-binning mode only"
+        assert bool((raw >> 31).all()), "default mode: every pair left in the list is flagged reachable"
+        e = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
+        scratch = (e(ctx.Cn, H, W), e(1, H, W), e(1, H, W), torch.empty(ctx.P, dtype=torch.int32, device=dev))
+        with R.full_binning():
+            a2 = R._fwd_args(rs, ctx.P, ctx.Cn, m3, shs, cols, opac, scl, rot, cov, bg, view, proj, campos, *scratch, None, 1)
+            geom2, image2, pl2, sr2, ql2, D2 = R._streaming_render(a2, dev, _lib.lib(), False)
+        assert D2 == D
+        fkeys, franges, fncontrib, fraw = _export_binning_of(a2, D2, pl2, W, H, dev)
+        assert len(fkeys) == D
+        fl = (fraw >> 31).astype(bool)
+        # (i) the culled list is the full list minus the unflagged pairs, in the same order
+        np.testing.assert_array_equal(keys, fkeys[fl], err_msg="culled keys != full keys filtered by the reach flag")
+        np.testing.assert_array_equal(raw & np.uint32(0x7FFFFFFF), (fraw & np.uint32(0x7FFFFFFF))[fl])
+        kept_before = np.concatenate([[0], np.cumsum(fl)]).astype(np.uint32)          # kept entries before full position i
+        want = np.stack([kept_before[franges[:, 0]], kept_before[franges[:, 1]]], axis=1)
+        want[want[:, 0] == want[:, 1]] = 0                 # a tile that kept nothing has the empty range (0, 0), as an untouched tile
+        np.testing.assert_array_equal(ranges, want, err_msg="culled tile ranges != ranges of the filtered list")
+        # (iii) same images bit for bit, same last contributor per pixel
+        assert torch.equal(scratch[0], color_tensor.detach()), "colour differs between the culled and the full pass"
+        assert torch.equal(scratch[2], alpha), "alpha differs between the culled and the full pass"
+        assert torch.equal(scratch[3], radii)
+        gx = (W + 15) // 16
+        tile_of_px = ((np.arange(H)[:, None] // 16) * gx + (np.arange(W)[None, :] // 16)).astype(np.int64)
+        full_pos_of_kept = np.nonzero(fl)[0].astype(np.int64)
+        nz = ncontrib > 0
+        g_culled = ranges[tile_of_px, 0].astype(np.int64) + ncontrib.astype(np.int64) - 1
+        mapped = np.zeros_like(fncontrib)
+        mapped[nz] = (full_pos_of_kept[g_culled[nz]] - franges[tile_of_px, 0].astype(np.int64)[nz] + 1).astype(np.uint32)
+        np.testing.assert_array_equal(mapped, fncontrib, err_msg="n_contrib of the culled pass does not map onto the full pass'")
+        keys, ranges, ncontrib, raw = fkeys, franges, fncontrib, fraw
     # sorted values: Gaussian id in bits 0..30, bit 31 = "the pair can reach a pixel of its tile" (csrc/ogs_common.h)
-    raw = point_list[:D].cpu().numpy().view(np.uint32)
     LAST_REACH_FLAGS[:] = [(raw >> 31).astype(bool)]
-    return (keys[:D].cpu().numpy().view(np.uint64), ranges.cpu().numpy().view(np.uint32),
-            ncontrib.cpu().numpy().view(np.uint32), raw & np.uint32(0x7FFFFFFF))
+    return keys, ranges, ncontrib, raw & np.uint32(0x7FFFFFFF)
 
 
 LAST_REACH_FLAGS = [None]       # reach flags of the most recent hip_export_binning call, parallel to its point list

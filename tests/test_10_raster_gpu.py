@@ -243,6 +243,41 @@ def test_backward_parity_6ch(gpu_device):
         assert e < GRAD_TOL, f"{k}: relative error {e} (all: {errs})"
 
 
+def test_dropping_unreachable_pairs_changes_no_image_and_no_gradient(gpu_device):
+    """Default mode: the (Gaussian, tile) pairs that cannot reach a pixel of their tile leave the list before the tile sort
+    (OgsRasterFwdArgs.full_binning = 0).  Against the same pass with the reference's full list (`rasterizer.full_binning()`):
+    every image and every gradient BIT for bit -- the dropped pairs contributed nothing, and the surviving ones are blended and
+    folded in the same order.  (The list itself is checked entry by entry in helpers.hip_export_binning.)"""
+    from opengaussian_amd import rasterizer as R
+    from opengaussian_amd.rasterizer import rasterize_fused
+    W, H, f, P = 176, 112, 130.0, 3000
+    sc, cam = helpers.tiny_scene(P, W, H, f, seed=21)
+    dev = gpu_device
+    rs = helpers.settings_for(cam, (0.1, 0.0, 0.2), 3, dev)
+    g = torch.Generator().manual_seed(6)
+    gCF, gA, gD = (torch.randn(9, H, W, generator=g).to(dev), torch.randn(1, H, W, generator=g).to(dev),
+                   torch.randn(1, H, W, generator=g).to(dev))
+
+    def run():
+        lv = {k: getattr(sc, k).clone().to(dev).requires_grad_(True)
+              for k in ("means3D", "scales", "rotations", "opacities", "shs", "ins_feat")}
+        m2 = torch.zeros(P, 3, device=dev, requires_grad=True)
+        c, r, d, a = rasterize_fused(lv["means3D"], m2, lv["opacities"], lv["shs"], lv["ins_feat"], rs, scales=lv["scales"],
+                                     rotations=lv["rotations"])
+        torch.autograd.backward([c, a, d], [gCF, gA, gD])
+        return (c, r, d, a), {**{k: v.grad for k, v in lv.items()}, "means2D": m2.grad}, c.grad_fn
+
+    assert R.FULL_BINNING is False
+    out_c, grad_c, fn_c = run()
+    with R.full_binning():
+        out_f, grad_f, fn_f = run()
+    assert fn_c.full_binning is False and fn_f.full_binning is True and fn_c.num_rendered == fn_f.num_rendered
+    for x, y in zip(out_c, out_f):
+        assert torch.equal(x, y)
+    for k in grad_c:
+        assert grad_c[k] is not None and torch.equal(grad_c[k], grad_f[k]), k
+
+
 def test_fused_pass_equals_separate_passes(gpu_device):
     """rasterize_fused (RGB via SH + 6-D ins_feat in ONE pass, feature loss detached from geometry) must give
     what the reference's separate passes give: pass A = RGB with all gradients, pass B = 6 feature channels
