@@ -459,23 +459,37 @@ __global__ __launch_bounds__(kBlock) void radix_onesweep_kernel(const uint32_t* 
     }
 }
 
+constexpr int kRangeItems = 4;               // consecutive keys per thread: one 16-byte load + the key in front of them
 __global__ __launch_bounds__(kBlock) void tile_ranges_kernel(const uint32_t* __restrict__ tile_keys, int64_t D_cap,
                                                              const uint32_t* __restrict__ n_dev,
                                                              uint2* __restrict__ ranges) {
     const int64_t D = n_dev ? min((int64_t)*n_dev, D_cap) : D_cap;
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= D) return;
-    const uint32_t cur = tile_keys[i];
-    if (i == 0) {
-        ranges[cur].x = 0;
+    const int64_t i0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kRangeItems;
+    if (i0 >= D) return;
+    uint32_t k[kRangeItems];
+    if (i0 + kRangeItems <= D) {
+        const uint4 v = *reinterpret_cast<const uint4*>(tile_keys + i0);      // the key buffers are 256-byte aligned
+        k[0] = v.x; k[1] = v.y; k[2] = v.z; k[3] = v.w;
     } else {
-        const uint32_t prev = tile_keys[i - 1];
-        if (prev != cur) {
-            ranges[prev].y = (uint32_t)i;
-            ranges[cur].x = (uint32_t)i;
+#pragma unroll
+        for (int j = 0; j < kRangeItems; ++j) k[j] = i0 + j < D ? tile_keys[i0 + j] : 0u;
+    }
+    uint32_t prev = i0 > 0 ? tile_keys[i0 - 1] : 0u;
+#pragma unroll
+    for (int j = 0; j < kRangeItems; ++j) {
+        const int64_t i = i0 + j;
+        if (i < D) {
+            const uint32_t cur = k[j];
+            if (i == 0) {
+                ranges[cur].x = 0;
+            } else if (prev != cur) {
+                ranges[prev].y = (uint32_t)i;
+                ranges[cur].x = (uint32_t)i;
+            }
+            if (i == D - 1) ranges[cur].y = (uint32_t)D;
+            prev = cur;
         }
     }
-    if (i == D - 1) ranges[cur].y = (uint32_t)D;
 }
 
 __global__ __launch_bounds__(kBlock) void export_keys_kernel(const uint2* __restrict__ ranges,
@@ -673,7 +687,7 @@ int launch_tile_ranges(const uint32_t* tile_keys_sorted, int64_t D, uint2* range
                        int debug, const uint32_t* n_dev) {
     OGS_HIP_CHECK(hipMemsetAsync(ranges, 0, (size_t)tiles * sizeof(uint2), s));
     if (D <= 0) return OGS_OK;
-    const int grid = (int)((D + kBlock - 1) / kBlock);
+    const int grid = (int)((D + (int64_t)kBlock * kRangeItems - 1) / ((int64_t)kBlock * kRangeItems));
     OGS_LAUNCH(tile_ranges_kernel, dim3(grid), dim3(kBlock), 0, s, tile_keys_sorted, D, n_dev, ranges);
     OGS_LAUNCH_CHECK(debug, s);
     return OGS_OK;
