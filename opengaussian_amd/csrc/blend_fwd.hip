@@ -382,22 +382,22 @@ __device__ __forceinline__ void blend_rows_tile(
         const float h = rec.at(5);
         const bool cand = fabsf(power + h) <= h;
         if (__ballot(cand) != 0ull) {
-            bool stop = false;
-            if (cand) {
-                float alpha = fminf(0.99f, rec.at(6) * __expf(power));
-                alpha = alpha >= kAlphaMin ? alpha : 0.f;
-                const float test_T = T * (1.0f - alpha);
-                stop = test_T < 0.0001f;
-                const float w = stop ? 0.f : alpha * T;
-                const v2f w2 = {w, w};
+            // straight-line for all 64 lanes (no exec-mask region: a lane that is no candidate gets alpha = 0, which leaves
+            // every one of its accumulators, its T and its `last` untouched -- w = 0, test_T = T >= 1e-4 -- so the values of
+            // the contributing lanes are the same operations on the same operands as before)
+            float alpha = fminf(0.99f, rec.at(6) * __expf(power));
+            alpha = (cand && alpha >= kAlphaMin) ? alpha : 0.f;
+            const float test_T = T * (1.0f - alpha);
+            const bool stop = test_T < 0.0001f;
+            const float w = stop ? 0.f : alpha * T;
+            const v2f w2 = {w, w};
 #pragma unroll
-                for (int k = 0; k < NPF; ++k)
-                    accp[k] = __builtin_elementwise_fma((v2f){rec.feat(2 * k), rec.feat(2 * k + 1)}, w2, accp[k]);
-                wacc += w;
-                T = stop ? T : test_T;
-                last = w > 0.f ? jplus1 : last;
-                fxe = stop ? kFar : fxe;
-            }
+            for (int k = 0; k < NPF; ++k)
+                accp[k] = __builtin_elementwise_fma((v2f){rec.feat(2 * k), rec.feat(2 * k + 1)}, w2, accp[k]);
+            wacc += w;
+            T = stop ? T : test_T;
+            last = w > 0.f ? jplus1 : last;
+            fxe = stop ? kFar : fxe;
             if (__ballot(stop) != 0ull) all_done = __ballot(fxe < kFarTest) == 0ull;
         }
     };
@@ -427,32 +427,37 @@ __device__ __forceinline__ void blend_rows_tile(
             }
         }
         // ---- 2. four compacted lists (row b's list: chunk slots that can reach block b), padded with the dummy ----
+        // list entry = chunk slot << 16 | byte offset of the slot's record in the wave's LDS region (no multiply in the walk)
+        constexpr uint32_t kDummy = (64u << 16) | (64u * NV4 * 16u);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) s_list[wave][b][lane] = 64u;
+        for (int b = 0; b < 4; ++b) s_list[wave][b][lane] = kDummy;
         if (lane < kListLen - kWave) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) s_list[wave][b][kWave + lane] = 64u;
+            for (int b = 0; b < 4; ++b) s_list[wave][b][kWave + lane] = kDummy;
         }
         int maxlen = 0;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const uint64_t mask = __ballot(reach[b]);
             const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            if (reach[b]) s_list[wave][b][pos] = (uint32_t)lane;
+            if (reach[b]) s_list[wave][b][pos] = ((uint32_t)lane << 16) | ((uint32_t)lane * NV4 * 16u);
             maxlen = max(maxlen, (int)__popcll(mask));
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // ---- 3. the four rows walk their lists; records two register sets, indices two steps ahead ----
         RowRec<C> ra, rb;
+        auto rec_of = [&](uint32_t e) {
+            return reinterpret_cast<const float4*>(reinterpret_cast<const char*>(recs) + (e & 0xFFFFu));
+        };
         uint32_t e0 = mylist[0], e1 = mylist[1];
-        ra.load_lds(recs + e0 * NV4);
+        ra.load_lds(rec_of(e0));
         for (int t = 0; t < maxlen && !all_done; t += 2) {
             const uint32_t e2 = mylist[t + 2], e3 = mylist[t + 3];
-            rb.load_lds(recs + e1 * NV4);
-            consume(ra, (uint32_t)c0 + e0 + 1u);
-            ra.load_lds(recs + e2 * NV4);
-            if (t + 1 < maxlen) consume(rb, (uint32_t)c0 + e1 + 1u);
+            rb.load_lds(rec_of(e1));
+            consume(ra, (uint32_t)c0 + (e0 >> 16) + 1u);
+            ra.load_lds(rec_of(e2));
+            if (t + 1 < maxlen) consume(rb, (uint32_t)c0 + (e1 >> 16) + 1u);
             e0 = e2; e1 = e3;
         }
         __builtin_amdgcn_wave_barrier();

@@ -1,4 +1,4 @@
-# A/B runs of bench.py under different environments on one box: edit the `run` lines
+# A/B runs of bench.py under different environments / libraries on one box: edit the `run` lines
 cd $GRAFT_REPO_ROOT
 run() {  # name, env...
   name=$1; shift
@@ -6,8 +6,9 @@ run() {  # name, env...
   python - $name <<'PY'
 import json, sys
 d = json.load(open(f"gpurun_out/ab_{sys.argv[1]}.json"))
-k = {a: round(b, 4) for a, b in d["kernels_ms_per_step"].items()}
+k = {a: round(b, 4) for a, b in d["kernels_ms_per_step"].items() if "blend" in a}
 print(sys.argv[1], round(d["ms_per_step"], 4), "stage1", round(d["stage1_pass"]["ms_per_step"], 4), k)
 PY
 }
-run cull && run full OGS_FULL_BINNING=1 && run cull2 && run full2 OGS_FULL_BINNING=1
+timeout -k 10 600 python -m pytest tests/test_10_raster_gpu.py -x -q -m gpu -k "forward_parity or tiny or adversarial or dropping" 2>&1 | tail -3 && \
+run new && run old OGS_LIB_PATH=$GRAFT_REPO_ROOT/gpurun_in/libogs_prev.so && run new2 && run old2 OGS_LIB_PATH=$GRAFT_REPO_ROOT/gpurun_in/libogs_prev.so
