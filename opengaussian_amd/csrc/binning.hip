@@ -684,8 +684,8 @@ int radix_pass(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_
 }
 
 int launch_tile_ranges(const uint32_t* tile_keys_sorted, int64_t D, uint2* ranges, int64_t tiles, hipStream_t s,
-                       int debug, const uint32_t* n_dev) {
-    OGS_HIP_CHECK(hipMemsetAsync(ranges, 0, (size_t)tiles * sizeof(uint2), s));
+                       int debug, const uint32_t* n_dev, bool already_zeroed) {
+    if (!already_zeroed) OGS_HIP_CHECK(hipMemsetAsync(ranges, 0, (size_t)tiles * sizeof(uint2), s));
     if (D <= 0) return OGS_OK;
     const int grid = (int)((D + (int64_t)kBlock * kRangeItems - 1) / ((int64_t)kBlock * kRangeItems));
     OGS_LAUNCH(tile_ranges_kernel, dim3(grid), dim3(kBlock), 0, s, tile_keys_sorted, D, n_dev, ranges);

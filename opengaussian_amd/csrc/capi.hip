@@ -225,6 +225,9 @@ int ogs_raster_forward_geometry(const OgsRasterFwdArgs* a, void* stream_, int64_
     return OGS_OK;
 }
 
+// A one-thread kernel storing the word into the mapped pinned buffer instead of this 4-byte copy was tried (round 3: the copy costs
+// 6 us idle + 4 us blit + 6 us idle between the scan and duplicate_kernel in the kernel trace): no gain at S1M and 0.28 -> 0.38 ms
+// at C2 -- a kernel that writes host memory ends with a system-scope release, i.e. an L2 write-back the next kernels pay for.
 int ogs_raster_read_num_rendered_async(const OgsRasterFwdArgs* a, void* stream_, uint32_t* host_pinned) {
     if (!a || !host_pinned) { set_error("read_num_rendered_async: NULL pointer"); return OGS_ERR_INVALID_ARG; }
     if (a->P == 0) { *host_pinned = 0; return OGS_OK; }
@@ -265,7 +268,9 @@ static int render_impl(const OgsRasterFwdArgs* a, int64_t D, bool deferred, hipS
         // in the order the full list has them.  args.full_binning != 0 keeps the reference's full list (the dropped pairs stay,
         // flagged in bit 31 of the value, and pack skips them): what ogs_raster_export_binning hands to the parity tests.
         const bool cull = a->full_binning == 0;
-        rc = launch_duplicate(*a, gs, gt, bt.tile_keys[0], vbuf[0], (uint32_t)D, cull, s);
+        const bool zero_in_dup = tiles <= (int64_t)a->P;          // one thread per range to clear
+        rc = launch_duplicate(*a, gs, gt, bt.tile_keys[0], vbuf[0], (uint32_t)D, cull, s, zero_in_dup ? is.ranges : nullptr,
+                              zero_in_dup ? (int)tiles : 0);
         if (rc != OGS_OK) return rc;
         const bool sweep = radix_onesweep_enabled(D);
         int shifts[4], nbits[4];
@@ -286,7 +291,7 @@ static int render_impl(const OgsRasterFwdArgs* a, int64_t D, bool deferred, hipS
                        : radix_pass(bt.tile_keys[in], vbuf[in], bt.tile_keys[out], vbuf[out], D, shifts[p], nbits[p], bt.sort_tmp, s, a->debug, n_pass, drop, drop ? bt.kept : nullptr);
             if (rc != OGS_OK) return rc;
         }
-        rc = launch_tile_ranges(bt.tile_keys[passes & 1], D, is.ranges, tiles, s, a->debug, cull ? bt.kept : n_dev);
+        rc = launch_tile_ranges(bt.tile_keys[passes & 1], D, is.ranges, tiles, s, a->debug, cull ? bt.kept : n_dev, zero_in_dup);
         if (rc != OGS_OK) return rc;
     } else {
         OGS_HIP_CHECK(hipMemsetAsync(is.ranges, 0, (size_t)tiles * sizeof(uint2), s));

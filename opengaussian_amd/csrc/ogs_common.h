@@ -287,10 +287,12 @@ int launch_preprocess(const OgsRasterFwdArgs& a, const GeomState& gs, const Geom
 int launch_tiny_geometry(const OgsRasterFwdArgs& a, const GeomState& gs, uint32_t* order, hipStream_t s);
 int launch_small_geometry(const OgsRasterFwdArgs& a, const GeomState& gs, const GeomTmp& gt, hipStream_t s);
 int launch_tiny_blend(const OgsRasterFwdArgs& a, const GeomState& gs, const uint32_t* order, hipStream_t s);
+// zero_ranges / n_zero (optional, n_zero <= P): the kernel also clears that many tile ranges (then launch_tile_ranges is told so)
 int launch_duplicate(const OgsRasterFwdArgs& a, const GeomState& gs, const GeomTmp& gt, uint32_t* tile_keys,
-                     uint32_t* vals, uint32_t capacity, bool drop_unreachable, hipStream_t s);
+                     uint32_t* vals, uint32_t capacity, bool drop_unreachable, hipStream_t s, uint2* zero_ranges = nullptr,
+                     int n_zero = 0);
 int launch_tile_ranges(const uint32_t* tile_keys_sorted, int64_t D, uint2* ranges, int64_t tiles, hipStream_t s,
-                       int debug, const uint32_t* n_dev = nullptr);
+                       int debug, const uint32_t* n_dev = nullptr, bool already_zeroed = false);
 inline int num_groups_of(int g) { return g > 1 ? g : 1; }
 int launch_blend_forward(const OgsRasterFwdArgs& a, const GeomState& gs, const ImageState& is, int64_t D,
                          hipStream_t s);

@@ -369,7 +369,8 @@ __global__ __launch_bounds__(kBlock) void duplicate_kernel(int P, int W, int H, 
                                                            const uint32_t* __restrict__ offsets,
                                                            uint32_t* __restrict__ tile_keys,
                                                            uint32_t* __restrict__ vals, uint32_t capacity,
-                                                           const int32_t* __restrict__ group_ids, bool drop_unreachable) {
+                                                           const int32_t* __restrict__ group_ids, bool drop_unreachable,
+                                                           uint2* __restrict__ zero_ranges, int n_zero) {
     // drop_unreachable: a pair that cannot reach a pixel of its tile gets the key kDropKey, which the first pass of the tile
     // sort leaves out (binning.hip) -- the sorted list then holds the reachable pairs only.  Otherwise the pair keeps its tile
     // key and only its reach flag (bit 31 of the value) tells pack to skip it: the reference's full list (args.full_binning).
@@ -391,6 +392,9 @@ __global__ __launch_bounds__(kBlock) void duplicate_kernel(int P, int W, int H, 
     __shared__ float4 s_con[kBlock];        // conic A, C, -B / A, -B / C
     const int tid = threadIdx.x;
     const int r = blockIdx.x * kBlock + tid;
+    // the tile ranges start from zero (tile_ranges_kernel only writes the tiles that appear): cleared here, by a kernel that
+    // runs before the sort anyway, instead of by a memset launch of its own
+    if (zero_ranges != nullptr && r < n_zero) zero_ranges[r] = make_uint2(0u, 0u);
     const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
     uint32_t off = 0, cnt = 0, gid = 0, rect = 1u << 24, key0 = 0;
     float4 ctr = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -561,7 +565,8 @@ int launch_preprocess(const OgsRasterFwdArgs& a, const GeomState& gs, const Geom
 }
 
 int launch_duplicate(const OgsRasterFwdArgs& a, const GeomState& gs, const GeomTmp& gt, uint32_t* tile_keys,
-                     uint32_t* vals, uint32_t capacity, bool drop_unreachable, hipStream_t s) {
+                     uint32_t* vals, uint32_t capacity, bool drop_unreachable, hipStream_t s, uint2* zero_ranges, int n_zero) {
+    if (n_zero > a.P) { set_error("duplicate: %d ranges to clear with %d threads", n_zero, a.P); return OGS_ERR_INVALID_ARG; }
     const int grid = (a.P + kBlock - 1) / kBlock;
     const int32_t* grp = a.num_groups > 1 ? a.group_ids : nullptr;
     if ((a.W + kTile - 1) / kTile > 4095 || (a.H + kTile - 1) / kTile > 4095) {
@@ -569,9 +574,9 @@ int launch_duplicate(const OgsRasterFwdArgs& a, const GeomState& gs, const GeomT
         return OGS_ERR_UNSUPPORTED;
     }
     switch (rec_vec4(a.C)) {
-        case 3: OGS_LAUNCH(duplicate_kernel<3>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals, capacity, grp, drop_unreachable); break;
-        case 4: OGS_LAUNCH(duplicate_kernel<4>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals, capacity, grp, drop_unreachable); break;
-        case 5: OGS_LAUNCH(duplicate_kernel<5>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals, capacity, grp, drop_unreachable); break;
+        case 3: OGS_LAUNCH(duplicate_kernel<3>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals, capacity, grp, drop_unreachable, zero_ranges, n_zero); break;
+        case 4: OGS_LAUNCH(duplicate_kernel<4>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals, capacity, grp, drop_unreachable, zero_ranges, n_zero); break;
+        case 5: OGS_LAUNCH(duplicate_kernel<5>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals, capacity, grp, drop_unreachable, zero_ranges, n_zero); break;
         default: set_error("unsupported record size"); return OGS_ERR_UNSUPPORTED;
     }
     OGS_LAUNCH_CHECK(a.debug, s);

@@ -1,4 +1,4 @@
-# A/B runs of bench.py under different environments / libraries on one box: edit the `run` lines
+# A/B runs of bench.py under different environments / libraries on one box: edit the lines at the bottom
 cd $GRAFT_REPO_ROOT
 run() {  # name, env...
   name=$1; shift
@@ -6,9 +6,8 @@ run() {  # name, env...
   python - $name <<'PY'
 import json, sys
 d = json.load(open(f"gpurun_out/ab_{sys.argv[1]}.json"))
-k = {a: round(b, 4) for a, b in d["kernels_ms_per_step"].items() if "blend" in a}
-print(sys.argv[1], round(d["ms_per_step"], 4), "stage1", round(d["stage1_pass"]["ms_per_step"], 4), k)
+print(sys.argv[1], round(d["ms_per_step"], 4), "stage1", round(d["stage1_pass"]["ms_per_step"], 4))
 PY
 }
-timeout -k 10 600 python -m pytest tests/test_10_raster_gpu.py -x -q -m gpu -k "forward_parity or tiny or adversarial or dropping" 2>&1 | tail -3 && \
-run new && run old OGS_LIB_PATH=$GRAFT_REPO_ROOT/gpurun_in/libogs_prev.so && run new2 && run old2 OGS_LIB_PATH=$GRAFT_REPO_ROOT/gpurun_in/libogs_prev.so
+c2() { env "$@" timeout -k 10 300 python bench.py --workload C2-100k-800 --steps 300 --warmup 20 --no-extra-workloads --no-cpu-baseline --no-kmeans 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('C2', sys.argv[1:], d['ms_per_step'])" "$@"; }
+timeout -k 10 900 python -m pytest tests/test_10_raster_gpu.py tests/test_11_render_gpu.py -x -q -m gpu 2>&1 | tail -3 && run new && c2 A=new && run new2 && c2 A=new
