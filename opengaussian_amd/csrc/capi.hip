@@ -278,6 +278,11 @@ static int render_impl(const OgsRasterFwdArgs* a, int64_t D, bool deferred, hipS
             shifts[p] = p * per;
             nbits[p] = (p == passes - 1) ? (bits == 0 ? 1 : bits - shifts[p]) : per;
         }
+        if (passes == 2 && (bits & 1)) {
+            // odd digit total: the SMALLER digit goes first -- the first pass ranks every pair, the second only those that survive
+            // the drop (13 bits: 6 + 7 instead of 7 + 6, a few us on the scatters)
+            nbits[0] = bits / 2; shifts[1] = nbits[0]; nbits[1] = bits - nbits[0];
+        }
         if (sweep) {
             rc = radix_sort_begin(bt.tile_keys[0], D, n_dev, passes, shifts, nbits, bt.sort_tmp, s, a->debug, cull);
             if (rc != OGS_OK) return rc;
