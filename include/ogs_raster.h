@@ -77,8 +77,10 @@ typedef struct OgsRasterFwdArgs {
     void* geom_buffer;           /* ogs_raster_geom_bytes(P, C): kept until backward */
     void* geom_tmp;              /* ogs_raster_geom_tmp_bytes(P): must live across both forward calls */
     void* image_buffer;          /* ogs_raster_image_bytes(W, H): kept until backward */
-    uint32_t* point_list;        /* [num_rendered] sorted Gaussian ids in bits 0..30; bit 31: the (Gaussian, tile) pair can
-                                  * reach a pixel of its tile (P < 2^31).  Kept until backward (render phase) */
+    uint32_t* point_list;        /* capacity [num_rendered]: sorted Gaussian ids in bits 0..30; bit 31: the (Gaussian, tile) pair
+                                  * can reach a pixel of its tile (P < 2^31).  Default mode: only the reachable pairs are listed
+                                  * (the tile ranges say how many); full_binning != 0: all num_rendered pairs.  Kept until
+                                  * backward (render phase) */
     void* binning_tmp;           /* ogs_raster_binning_tmp_bytes(num_rendered, W, H) (render phase) */
     void* sorted_rec;            /* ogs_raster_sorted_bytes(num_rendered, C): one packed record per sorted-list entry,
                                     read by the blend kernels through the scalar path; kept until backward */
@@ -227,8 +229,10 @@ int ogs_sh_grad_from_views(int32_t P, int32_t V, int32_t sh_degree, int32_t sh_c
                            const float* campos, const float* dL_drgb, float* dL_dsh, void* stream);
 
 /* Test/diagnostic export of the binning state the reference keeps in its binningBuffer /
- * imgBuffer: the sorted 64-bit keys (tile << 32 | float_bits(depth)) [num_rendered], the per-tile
- * ranges [T,2] and n_contrib [H,W].  Any output may be NULL. */
+ * imgBuffer: the sorted 64-bit keys (tile << 32 | float_bits(depth)) [capacity num_rendered], the per-tile
+ * ranges [T,2] and n_contrib [H,W].  Any output may be NULL.  The lists are those of the pass: after a pass with
+ * args.full_binning != 0 the reference's full lists (num_rendered entries, n_contrib = position in the tile's full list);
+ * after a default pass the reachable pairs only (ranges[T-1].y entries; n_contrib = position in that shorter list). */
 int ogs_raster_export_binning(const OgsRasterFwdArgs* args, int64_t num_rendered, uint64_t* keys_out,
                               uint32_t* ranges_out, uint32_t* n_contrib_out, void* stream);
 
