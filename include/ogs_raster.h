@@ -232,7 +232,7 @@ int ogs_sh_grad_from_views(int32_t P, int32_t V, int32_t sh_degree, int32_t sh_c
  * imgBuffer: the sorted 64-bit keys (tile << 32 | float_bits(depth)) [capacity num_rendered], the per-tile
  * ranges [T,2] and n_contrib [H,W].  Any output may be NULL.  The lists are those of the pass: after a pass with
  * args.full_binning != 0 the reference's full lists (num_rendered entries, n_contrib = position in the tile's full list);
- * after a default pass the reachable pairs only (ranges[T-1].y entries; n_contrib = position in that shorter list). */
+ * after a default pass the reachable pairs only (max over the tiles of ranges[t].y entries; n_contrib = position in that shorter list). */
 int ogs_raster_export_binning(const OgsRasterFwdArgs* args, int64_t num_rendered, uint64_t* keys_out,
                               uint32_t* ranges_out, uint32_t* n_contrib_out, void* stream);
 
