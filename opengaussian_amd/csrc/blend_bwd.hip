@@ -147,7 +147,9 @@ struct RankOneFold {
 //   cancellation of their own; the shift has the conditioning of the direct evaluation sum q d^2).
 // LDS: 16 rows x 68 floats per wave (row stride 68 words: 16-byte aligned rows for the ds_read_b128 of the flush, and
 // the sixteen rows of a lane group land in distinct bank groups).  Gaussian id and centre of the batch's entries live
-// in three VGPRs (entry e in lane e: a select per entry) and are fetched with ds_bpermute.
+// in three VGPRs (entry e in lane e: a select per entry); the flush parks them in the rows' spare columns and reads them back
+// per lane group (round 3; six ds_bpermute before: 0.654 -> 0.634 ms.  The same change on RankOneFold's four made the
+// features-only kernel slower, 0.363 -> 0.383 ms, and was not kept).
 constexpr int kPairStride = 68;
 struct PairFoldLds {
     float t[16 * kPairStride];
@@ -210,12 +212,22 @@ struct PairFold {
         }
         d = d + d1;
         const bool column_used = m < C || (DEPTH && m == kSlotDepth) || m >= kSlotMoments;
+        // id and centre of the batch's eight entries: lane e of the three stash registers -> the spare columns 64..66 of row e
+        // -> each lane group reads the two entries it owns (one masked 12-byte write + two 16-byte reads instead of six
+        // ds_bpermute at 24 issue cycles each: 144 of the ~900 cycles of a flush)
+        if (lane < 8) {
+            float* sp = t + lane * kPairStride + 64;
+            sp[0] = __uint_as_float(gidv); sp[1] = mxv; sp[2] = myv;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
             const int e = 2 * kq + rr;
-            const uint32_t g = (uint32_t)__builtin_amdgcn_ds_bpermute(e * 4, (int)gidv);
-            const float a = __int_as_float(__builtin_amdgcn_ds_bpermute(e * 4, __float_as_int(mxv))) - x0;
-            const float b = __int_as_float(__builtin_amdgcn_ds_bpermute(e * 4, __float_as_int(myv))) - y0;
+            const float4 sd = *reinterpret_cast<const float4*>(t + e * kPairStride + 64);
+            const uint32_t g = __float_as_uint(sd.x);
+            const float a = sd.y - x0;
+            const float b = sd.z - y0;
             const float own = d[2 + rr];
             const float M0 = row_bcast<kSlotMoments>(own), Mu = row_bcast<kSlotMoments + 1>(own),
                         Mv = row_bcast<kSlotMoments + 2>(own);

@@ -6,8 +6,10 @@ run() {  # name, env...
   python - $name <<'PY'
 import json, sys
 d = json.load(open(f"gpurun_out/ab_{sys.argv[1]}.json"))
-k = {a: round(b, 4) for a, b in d["kernels_ms_per_step"].items() if "radix" in a and "16" in a or "pack" in a}
-print(sys.argv[1], round(d["ms_per_step"], 4), "stage1", round(d["stage1_pass"]["ms_per_step"], 4), k)
+k = {a: round(b, 4) for a, b in d["kernels_ms_per_step"].items() if "blend_b" in a}
+s = {a: round(b, 4) for a, b in d["stage1_pass"]["kernels_ms"].items() if "blend_b" in a}
+print(sys.argv[1], round(d["ms_per_step"], 4), "stage1", round(d["stage1_pass"]["ms_per_step"], 4), k, s)
 PY
 }
-run b7 && run b5 OGS_TILE_SORT_FIRST_BITS=5 && run b6 OGS_TILE_SORT_FIRST_BITS=6 && run b8 OGS_TILE_SORT_FIRST_BITS=8 && run b7b
+timeout -k 10 900 python -m pytest tests/test_10_raster_gpu.py -x -q -m gpu 2>&1 | tail -3 && \
+run new && run old OGS_LIB_PATH=$GRAFT_REPO_ROOT/gpurun_in/libogs_prev.so && run new2 && run old2 OGS_LIB_PATH=$GRAFT_REPO_ROOT/gpurun_in/libogs_prev.so
