@@ -239,7 +239,9 @@ struct PairFold {
             val = m == kSlotMoments + 4 ? (own + a * (tb - Mv)) - b * Mu : val;     // Sxy
             val = m == kSlotMoments + 5 ? own + b * (tb - 2.f * Mv) : val;          // Syy
             val = m < kSlotMoments ? d[rr] : val;                                   // feature / depth slots
-            if (e < cnt && column_used && !skip_atomics) atomicAdd(grad_rec + ((size_t)g * GS + m), (ACC)val);
+            // 32-bit element offset from the (uniform) record array: SGPR-base addressing, no 64-bit vector arithmetic (P < 2^28)
+            const uint32_t off = g * (uint32_t)GS + (uint32_t)m;
+            if (e < cnt && column_used && !skip_atomics) atomicAdd(grad_rec + off, (ACC)val);
         }
         cnt = 0;
     }
