@@ -15,6 +15,7 @@ channels; one pass then bins/sorts once and blends all channels (``color`` is [C
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import os
 from typing import NamedTuple, Optional
 
@@ -184,22 +185,36 @@ def _fwd_args(rs, P, Cn, m3, shs, cols, opac, scl, rot, cov, bg, view, proj, cam
     return a
 
 
+# scratch sizes are pure functions of the shape: asked once per shape, not six ctypes calls per pass (a 100 k-Gaussian step is
+# paced by the host)
+@functools.lru_cache(maxsize=256)
+def _geom_sizes(P, W, H, Cn, G):
+    lib = _lib.lib()
+    return (int(lib.ogs_raster_geom_bytes(P, Cn)), int(lib.ogs_raster_geom_tmp_bytes(P)),
+            int(lib.ogs_raster_image_bytes_grouped(W, H, G)))
+
+
+@functools.lru_cache(maxsize=1024)
+def _render_sizes(count, W, H, Cn):
+    lib = _lib.lib()
+    return (int(lib.ogs_raster_binning_tmp_bytes(count, W, H)), int(lib.ogs_raster_sorted_bytes(count, Cn)),
+            int(lib.ogs_raster_quad_list_bytes(count)))
+
+
 def _streaming_render(a: OgsRasterFwdArgs, dev, lib, debug: bool):
     """The two-phase forward (geometry -> num_rendered -> render) on the buffers `a` already points to for inputs
     and outputs; allocates and returns (geom, image, point_list, sorted_rec, quad_list, num_rendered)."""
     P, W, H, Cn, G = int(a.P), int(a.W), int(a.H), int(a.C), max(int(a.num_groups), 1)
     u8 = lambda n: torch.empty(int(n), dtype=torch.uint8, device=dev)
-    geom = u8(lib.ogs_raster_geom_bytes(P, Cn))
-    geom_tmp = u8(lib.ogs_raster_geom_tmp_bytes(P))
-    image = u8(lib.ogs_raster_image_bytes_grouped(W, H, G))
+    gb, gtb, ib = _geom_sizes(P, W, H, Cn, G)
+    geom, geom_tmp, image = u8(gb), u8(gtb), u8(ib)
     a.geom_buffer, a.geom_tmp, a.image_buffer = ptr(geom), ptr(geom_tmp), ptr(image)
     stream = _stream()
 
     def alloc_render(count):
+        btb, srb, qlb = _render_sizes(count, W, H, Cn)
         pl = torch.empty(max(count, 1), dtype=torch.int32, device=dev)
-        bt = u8(lib.ogs_raster_binning_tmp_bytes(count, W, H))
-        sr = u8(lib.ogs_raster_sorted_bytes(count, Cn))
-        ql = u8(lib.ogs_raster_quad_list_bytes(count))
+        bt, sr, ql = u8(btb), u8(srb), u8(qlb)
         a.point_list, a.binning_tmp, a.sorted_rec, a.quad_list = ptr(pl), ptr(bt), ptr(sr), ptr(ql)
         return pl, bt, sr, ql
 
