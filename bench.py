@@ -338,6 +338,11 @@ def main():
         raise SystemExit(self_launch(args))
     from opengaussian_amd import _lib, dp
     from opengaussian_amd import rasterizer as R
+    # backward on the calling thread: one process drives one GPU, so autograd's per-device worker thread only adds a thread hop per
+    # backward() -- invisible at S1M (device-bound), but a 100 k-Gaussian step is paced by the host: 0.35-0.47 -> 0.295-0.30 ms on
+    # one box (INTEGRATION.md recommends the same line to training scripts).  OGS_BENCH_AUTOGRAD_MT=1 restores torch's default.
+    autograd_mt = os.environ.get("OGS_BENCH_AUTOGRAD_MT", "0") == "1"
+    torch.autograd.set_multithreading_enabled(autograd_mt)
     from opengaussian_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_fused
     from opengaussian_amd.synthetic import make_scene, orbit_camera
 
@@ -690,6 +695,7 @@ def main():
             # how the render phase was sized during the timed steps: sync-free (capacity hint) vs blocking read-back
             # vs overflow (render phase enqueued twice); the timed value pays for every one of them
             "render_phase_sizing_timed": {k: stats_timed[k] - stats0[k] for k in stats_timed},
+            "host": {"autograd_multithreading": autograd_mt},
             "dist": dist_info,
             "roofline": roofline,
             "roofline_valu": valu,
