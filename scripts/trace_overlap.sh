@@ -2,7 +2,7 @@
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/tr; mkdir -p gpurun_out/tr
-rocprofv3 --kernel-trace -d gpurun_out/tr -o t -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-kmeans --no-extras --no-extra-workloads > gpurun_out/tr/log 2>&1
+rocprofv3 --kernel-trace -d gpurun_out/tr -o t -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-kmeans --no-extras --no-extra-workloads $BENCH_ARGS > gpurun_out/tr/log 2>&1
 python3 - <<'PY'
 import sqlite3, glob, re
 f = glob.glob("gpurun_out/tr/**/*_results.db", recursive=True)[0]
@@ -23,7 +23,7 @@ idx = [i for i, r in enumerate(rows) if "preprocess_geom" in r[0] or re.search(r
 if idx:
     i0 = idx[-1]
     t0 = rows[i0][1]
-    for r in rows[i0:i0 + 26]:
+    for r in rows[i0:i0 + 40]:
         nm = re.search(r"(\w+_kernel)", r[0])
         print("%-34s start %8.1f us  dur %7.1f us  queue %s stream %s" % (nm.group(1) if nm else r[0][:30], (r[1] - t0) / 1e3, (r[2] - r[1]) / 1e3, r[3], r[4]))
 PY
