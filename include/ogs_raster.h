@@ -257,8 +257,10 @@ int ogs_selftest_tile_order(const uint32_t* ranges, int64_t vtiles, uint32_t* or
 /* Test / measurement hook: the stable LSD radix sort of the binning phase on its own.
  * Sorts n (key, value) pairs on the low key_bits bits in ceil(key_bits / 8) passes, ping-ponging between buffers 0 and 1
  * (input in keys0 / vals0); *result_buffer (host) receives 0 or 1, the buffer pair holding the result.
- * variant 0: three launches per pass (histogram table, row scan, scatter); variant 1: one launch per pass (digit
- * histograms of all passes up front + decoupled look-back).  tmp: ogs_selftest_radix_tmp_bytes(n) bytes of scratch. */
+ * variant bit 0 clear: three launches per pass (histogram table, row scan, scatter); set: one launch per pass (digit
+ * histograms of all passes up front + decoupled look-back).  variant bit 1 set (n < 2^30): drop mode of the tile sort -- keys
+ * equal to 0xFFFFFFFF are left out by the first pass, the result is the stable sort of the others and their count comes back in
+ * bits 1.. of *result_buffer (bit 0: the buffer pair).  tmp: ogs_selftest_radix_tmp_bytes(n) bytes of scratch. */
 size_t ogs_selftest_radix_tmp_bytes(int64_t n);
 int ogs_selftest_radix_sort(uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, uint32_t* vals1, int64_t n, int32_t key_bits,
                             int32_t variant, void* tmp, int32_t* result_buffer, void* stream);

@@ -398,18 +398,28 @@ int ogs_selftest_radix_sort(uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, u
     const int passes = (key_bits + 7) / 8, per = (key_bits + passes - 1) / passes;
     int shifts[4], nbits[4];
     for (int p = 0; p < passes; ++p) { shifts[p] = p * per; nbits[p] = p == passes - 1 ? key_bits - shifts[p] : per; }
+    // variant bit 0: one launch per pass; bit 1: drop mode -- keys equal to 0xFFFFFFFF leave in the first pass (the tile sort of the
+    // default binning mode); the number of keys left is returned in bits 1.. of *result_buffer
+    const bool sweep = (variant & 1) != 0, drop = (variant & 2) != 0;
+    uint32_t* kept = nullptr;
+    if (drop) OGS_HIP_CHECK(hipMalloc(&kept, sizeof(uint32_t)));
     int rc = OGS_OK;
-    if (variant == 1) {
-        rc = radix_sort_begin(k[0], n, nullptr, passes, shifts, nbits, tmp, s, 0);
-        if (rc != OGS_OK) return rc;
-    }
-    for (int p = 0; p < passes; ++p) {
+    if (sweep) rc = radix_sort_begin(k[0], n, nullptr, passes, shifts, nbits, tmp, s, 0, drop);
+    for (int p = 0; p < passes && rc == OGS_OK; ++p) {
         const int in = p & 1, out = in ^ 1;
-        rc = variant == 1 ? radix_sort_pass(p, passes, k[in], v[in], k[out], v[out], n, shifts[p], nbits[p], tmp, s, 0)
-                          : radix_pass(k[in], v[in], k[out], v[out], n, shifts[p], nbits[p], tmp, s, 0);
-        if (rc != OGS_OK) return rc;
+        const bool d0 = drop && p == 0;
+        const uint32_t* n_pass = (drop && p > 0) ? kept : nullptr;
+        rc = sweep ? radix_sort_pass(p, passes, k[in], v[in], k[out], v[out], n, shifts[p], nbits[p], tmp, s, 0, n_pass, d0, d0 ? kept : nullptr)
+                   : radix_pass(k[in], v[in], k[out], v[out], n, shifts[p], nbits[p], tmp, s, 0, n_pass, d0, d0 ? kept : nullptr);
     }
-    *result_buffer = passes & 1;
+    uint32_t kept_host = 0;
+    if (drop) {
+        if (rc == OGS_OK && hipMemcpyAsync(&kept_host, kept, sizeof(uint32_t), hipMemcpyDeviceToHost, s) != hipSuccess) rc = OGS_ERR_HIP;
+        (void)hipStreamSynchronize(s);
+        (void)hipFree(kept);
+    }
+    if (rc != OGS_OK) return rc;
+    *result_buffer = (passes & 1) | (drop ? (int32_t)(kept_host << 1) : 0);
     return OGS_OK;
 }
 
