@@ -42,6 +42,8 @@ extern "C" {
 #define OGS_ERR_HIP (-2)
 #define OGS_ERR_UNSUPPORTED (-3)
 #define OGS_ERR_SCRATCH_TOO_SMALL (-4)
+#define OGS_ERR_DEVICE (-5)    /* a kernel of an earlier launch reported a condition it could not recover from (sticky status
+                                * word, ogs_check_async_status): the results since the last check are not valid */
 
 #define OGS_TILE 16            /* BLOCK_X = BLOCK_Y = 16 */
 #define OGS_MAX_CHANNELS 12    /* blended feature channels per pass: 3 (facade), 6, 9, 12 (fused) */
@@ -145,10 +147,11 @@ typedef struct OgsRasterBwdArgs {
     const uint32_t* point_list;
     const void* sorted_rec;      /* from forward */
     const void* quad_list;       /* from forward */
-    void* bwd_tmp;               /* ogs_raster_backward_tmp_bytes(P): zeroed by the call.  Holds the per-Gaussian gradient
+    void* bwd_tmp;               /* ogs_raster_backward_tmp_bytes(P): zeroed by the call.  P * 16 must stay below 2^32 (the blend
+                                    kernels address the record array with 32-bit element offsets): P < 2^28 = 268 M Gaussians,
+                                    larger P is rejected with OGS_ERR_UNSUPPORTED.  Holds the per-Gaussian gradient
                                     record, 16 fp64 running sums = 128 B (float atomics arrive in a different order every
-                                    run; an fp64 sum is order-insensitive to ~1e-16 and is rounded to fp32 once).
-                                    Environment OGS_GRAD_ACCUM=f32 selects 16 fp32 sums (A-B timing only). */
+                                    run; an fp64 sum is order-insensitive to ~1e-16 and is rounded to fp32 once). */
     float* dL_dmeans2D;          /* [P,3] (x,y in NDC units: pixel gradient * 0.5*W / 0.5*H; z = 0) */
     float* dL_dcolors;           /* same shape as colors_precomp: [P,C], or [P,C-3] in a fused SH pass */
     float* dL_dopacity;          /* [P] */
@@ -168,6 +171,16 @@ typedef struct OgsRasterBwdArgs {
 
 int ogs_version(void);
 const char* ogs_last_error(void);
+
+/* Sticky asynchronous device status.  The one-launch radix passes (sorts of <= 256 k keys) wait for each other by decoupled
+ * look-back; every wait is bounded, and a workgroup whose wait runs out ORs a bit into a word in pinned host memory, finishes
+ * without hanging and without writing out of bounds, and leaves a WRONG permutation behind.  The library reads and clears the
+ * word wherever the host already waits for the stream -- the blocking num_rendered read-back of ogs_raster_forward_geometry,
+ * the entry of every later ogs_raster_forward_geometry / ogs_raster_backward -- and returns OGS_ERR_DEVICE; a caller of the
+ * sync-free sequence (ogs_raster_read_num_rendered_async + _deferred) calls this after its own wait for the copy.  Returns
+ * OGS_OK when nothing was reported since the last check.  (No reference counterpart: cub's sort has no failure mode that
+ * returns.) */
+int ogs_check_async_status(void);
 
 size_t ogs_raster_geom_bytes(int32_t P, int32_t C);
 size_t ogs_raster_geom_tmp_bytes(int32_t P);
@@ -192,7 +205,7 @@ int ogs_raster_forward_render(const OgsRasterFwdArgs* args, int64_t num_rendered
  *   ogs_raster_read_num_rendered_async(args, stream, pinned)   enqueue the 4-byte D2H copy into PINNED host memory
  *   ogs_raster_forward_render_deferred(args, capacity, stream) buffers sized for `capacity` (e.g. 1.25x the last
  *        num_rendered); the binning kernels read the true count from device memory, entries past the capacity
- *        are dropped
+ *        are dropped; a true count of ZERO is fine (background image, empty ranges)
  * The caller waits for the copy (an event recorded after it), and if *pinned > capacity re-runs
  * ogs_raster_forward_render with exact buffers -- the only case in which the deferred images are incomplete. */
 int ogs_raster_read_num_rendered_async(const OgsRasterFwdArgs* args, void* stream, uint32_t* host_pinned);
@@ -260,10 +273,15 @@ int ogs_selftest_tile_order(const uint32_t* ranges, int64_t vtiles, uint32_t* or
  * variant bit 0 clear: three launches per pass (histogram table, row scan, scatter); set: one launch per pass (digit
  * histograms of all passes up front + decoupled look-back).  variant bit 1 set (n < 2^30): drop mode of the tile sort -- keys
  * equal to 0xFFFFFFFF are left out by the first pass, the result is the stable sort of the others and their count comes back in
- * bits 1.. of *result_buffer (bit 0: the buffer pair).  tmp: ogs_selftest_radix_tmp_bytes(n) bytes of scratch. */
+ * bits 1.. of *result_buffer (bit 0: the buffer pair).  variant bit 2 set: fault injection -- the look-back waits of the
+ * one-launch passes are bounded by zero polls, the call must return OGS_ERR_DEVICE.
+ * items: keys per thread of a one-launch pass, 4 (1024-key tiles) or 16 (4096-key tiles); 0 = chosen by n as the library does.
+ * n_dev (device, optional): the element count lives in device memory and n is the capacity the launches are sized for (the
+ * deferred render phase); *n_dev == 0 is legal.  tmp: ogs_selftest_radix_tmp_bytes(n) bytes of scratch. */
 size_t ogs_selftest_radix_tmp_bytes(int64_t n);
 int ogs_selftest_radix_sort(uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, uint32_t* vals1, int64_t n, int32_t key_bits,
-                            int32_t variant, void* tmp, int32_t* result_buffer, void* stream);
+                            int32_t variant, int32_t items, const uint32_t* n_dev, void* tmp, int32_t* result_buffer,
+                            void* stream);
 
 #ifdef __cplusplus
 }

@@ -87,7 +87,8 @@ SIGNATURES = {
     "ogs_selftest_wave_fold16": (C.c_int, [_vp, _vp, _vp]),
     "ogs_selftest_tile_order": (C.c_int, [_vp, C.c_int64, _vp, _vp]),
     "ogs_selftest_radix_tmp_bytes": (C.c_size_t, [C.c_int64]),
-    "ogs_selftest_radix_sort": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int32, C.c_int32, _vp, _vp, _vp]),
+    "ogs_selftest_radix_sort": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
+    "ogs_check_async_status": (C.c_int, []),
     "ogs_prof_enable": (C.c_int, [C.c_int]),
     "ogs_prof_filter": (C.c_int, [C.c_char_p]),
     "ogs_prof_collect": (C.c_int, [C.c_char_p, C.c_size_t]),

@@ -16,7 +16,7 @@ namespace ogs {
 
 namespace {
 
-constexpr size_t kSweepHeaderWords = 4 * 256 + 4 + 60;     // digit histograms, tickets, error word (+ pad)
+constexpr size_t kSweepHeaderWords = 4 * 256 + 4 + 60;     // digit histograms, tickets (+ pad)
 constexpr int kScanItems = 8;
 constexpr int kScanTile = kBlock * kScanItems;   // 2048 elements per workgroup
 
@@ -296,7 +296,11 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint32_t* _
 //     "Inter-workgroup communication" -- the count travels IN the flagged word, nothing else is handed off);
 //   * the tile a workgroup processes is a TICKET drawn at its start, never blockIdx: a workgroup only ever waits for
 //     smaller tickets, whose workgroups have already started (HIP promises no dispatch order), and they publish before
-//     they wait -- so every wait ends; each spin is bounded all the same (kSpinLimit -> err flag, garbage out, no hang);
+//     they wait -- so every wait ends; each spin is bounded all the same: past `spin_limit` polls the workgroup ORs
+//     kAsyncRadixSpin into the library's sticky status word (pinned host memory, ogs_common.h::async_status_word -- a
+//     system-scope atomic that only ever executes on this path), gives up the look-back and writes a wrong permutation
+//     INSIDE its output range (no hang, no stray write); the host raises on the next status check: the read-back every
+//     forward waits on, the entry of the next forward / backward, ogs_check_async_status (round 4);
 //   * stability: ticket order == memory order of the tiles, ranks inside a tile as in radix_scatter_kernel.
 constexpr uint32_t kStatAgg = 1u << 30, kStatInc = 2u << 30, kStatMask = (1u << 30) - 1u;
 constexpr int kSpinLimit = 1 << 22;
@@ -335,7 +339,8 @@ __global__ __launch_bounds__(kBlock) void radix_onesweep_kernel(const uint32_t* 
                                                                 const uint32_t* __restrict__ ghist /*[256], this pass*/,
                                                                 uint32_t* __restrict__ status /*[tiles][256], zeroed*/,
                                                                 uint32_t* __restrict__ ticket /*zeroed*/,
-                                                                uint32_t* __restrict__ err, bool drop,
+                                                                uint32_t* __restrict__ status_word /*sticky, pinned host*/,
+                                                                int spin_limit, bool drop,
                                                                 uint32_t* __restrict__ kept_out) {
     __shared__ uint32_t wave_hist_s[kBlock / kWave][256];
     __shared__ uint32_t scan_sums[4];
@@ -352,7 +357,13 @@ __global__ __launch_bounds__(kBlock) void radix_onesweep_kernel(const uint32_t* 
     for (int w = 0; w < kBlock / kWave; ++w) wave_hist_s[w][tid] = 0;
     __syncthreads();
     const uint32_t tile = s_ticket;
-    if ((int64_t)tile * (kBlock * ITEMS) >= n) return;      // (deferred sizing) nothing here, and nothing after it either
+    if ((int64_t)tile * (kBlock * ITEMS) >= n) {            // (deferred sizing) nothing here, and nothing after it either
+        // tile 0 only gets here with n == 0 (a deferred pass that found nothing visible): the later passes, the tile ranges
+        // and pack read the kept count from device memory, so it must be written on this path too (it was left
+        // as whatever torch.empty handed out -> ranges[] written at garbage tile ids)
+        if (kept_out != nullptr && tile == 0 && tid == 0) *kept_out = 0u;
+        return;
+    }
 
     const int64_t base = (int64_t)tile * (kBlock * ITEMS) + (int64_t)wave * (ITEMS * kWave);
     uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
@@ -428,7 +439,10 @@ __global__ __launch_bounds__(kBlock) void radix_onesweep_kernel(const uint32_t* 
             }
             pb -= used;
             if (!done && used < kLookBack) {
-                if (++spins > kSpinLimit) { *err = 1u; break; }
+                if (++spins > spin_limit) {
+                    __hip_atomic_fetch_or(status_word, kAsyncRadixSpin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
                 __builtin_amdgcn_s_sleep(1);
             }
         }
@@ -530,9 +544,10 @@ size_t sort_tmp_bytes(int64_t n) {
 }
 
 // keys per thread of a one-launch pass: the look-back chain grows with the number of tiles, so mid-size sorts take
-// 4096-key tiles earlier than the three-launch passes do (OGS_SWEEP_ITEMS=4|16 forces one for A-B runs)
-static int sweep_items_for(int64_t n) {
-    static const int forced = [] { const char* e = getenv("OGS_SWEEP_ITEMS"); return e ? atoi(e) : 0; }();
+// 4096-key tiles earlier than the three-launch passes do.  `forced` (4 or 16; 0 = by size) comes from the radix self-test hook
+// only -- the environment switch of round 3 (OGS_SWEEP_ITEMS) is gone: every tile size the library can be asked for is a
+// tested argument, and sort_tmp_bytes covers the smaller tile at any n ("the round-3 fault").
+static int sweep_items_for(int64_t n, int forced) {
     if (forced == 4 || forced == 16) return forced;
     return n <= (int64_t)(256 << 10) ? 4 : 16;
 }
@@ -555,16 +570,14 @@ namespace {
 struct SweepTmp {
     uint32_t* ghist;      // [4][256]
     uint32_t* ticket;     // [4]
-    uint32_t* err;        // [1]
     uint32_t* status[4];  // [tiles][256] each
     size_t zero_bytes;    // header + the status tables of the passes in use
-    static SweepTmp carve(void* tmp, int64_t n, int npass) {
+    static SweepTmp carve(void* tmp, int64_t n, int npass, int items_forced) {
         SweepTmp t;
         char* p = static_cast<char*>(tmp);
         t.ghist = reinterpret_cast<uint32_t*>(p);
         t.ticket = t.ghist + 4 * 256;
-        t.err = t.ticket + 4;
-        const int items = sweep_items_for(n);
+        const int items = sweep_items_for(n, items_forced);
         const int64_t tiles = ((n > 0 ? n : 1) + (int64_t)kBlock * items - 1) / ((int64_t)kBlock * items);
         const size_t table = align_up((size_t)256 * tiles * sizeof(uint32_t));
         char* q = p + align_up(kSweepHeaderWords * sizeof(uint32_t));
@@ -577,10 +590,10 @@ struct SweepTmp {
 
 // Start of a sort of `npass` digit passes over the SAME multiset of keys: zero the scratch, histogram every digit.
 int radix_sort_begin(const uint32_t* keys, int64_t n, const uint32_t* n_dev, int npass, const int* shifts, const int* bits,
-                     void* tmp, hipStream_t stream, int debug, bool drop) {
+                     void* tmp, hipStream_t stream, int debug, bool drop, int items) {
     if (n <= 0) return OGS_OK;
     if (npass < 1 || npass > 4) { set_error("radix_sort_begin: npass=%d out of range", npass); return OGS_ERR_INVALID_ARG; }
-    const SweepTmp t = SweepTmp::carve(tmp, n, npass);
+    const SweepTmp t = SweepTmp::carve(tmp, n, npass, items);
     OGS_HIP_CHECK(hipMemsetAsync(tmp, 0, t.zero_bytes, stream));
     RadixPlanDev plan{};
     plan.npass = npass;
@@ -599,17 +612,22 @@ int radix_sort_begin(const uint32_t* keys, int64_t n, const uint32_t* n_dev, int
 // Pass `pass` (0-based, as planned in radix_sort_begin) of the sort: ONE launch.
 int radix_sort_pass(int pass, int npass, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
                     int64_t n, int shift, int bits, void* tmp, hipStream_t stream, int debug, const uint32_t* n_dev, bool drop,
-                    uint32_t* kept_out) {
+                    uint32_t* kept_out, int items_forced, int spin_limit) {
     if (n <= 0) return OGS_OK;
-    const SweepTmp t = SweepTmp::carve(tmp, n, npass);
-    const int items = sweep_items_for(n);
+    const SweepTmp t = SweepTmp::carve(tmp, n, npass, items_forced);
+    const int items = sweep_items_for(n, items_forced);
     const int nb = (int)((n + (int64_t)kBlock * items - 1) / ((int64_t)kBlock * items));
+    uint32_t* status_word = async_status_word();
+    if (!status_word) return OGS_ERR_HIP;
+    if (spin_limit < 0) spin_limit = kSpinLimit;
     if (items == 4) {
         OGS_LAUNCH(radix_onesweep_kernel<4>, dim3(nb), dim3(kBlock), 0, stream, keys_in, vals_in, keys_out, vals_out, n, n_dev,
-                   shift, bits, (const uint32_t*)(t.ghist + pass * 256), t.status[pass], t.ticket + pass, t.err, drop, kept_out);
+                   shift, bits, (const uint32_t*)(t.ghist + pass * 256), t.status[pass], t.ticket + pass, status_word, spin_limit,
+                   drop, kept_out);
     } else {
         OGS_LAUNCH(radix_onesweep_kernel<16>, dim3(nb), dim3(kBlock), 0, stream, keys_in, vals_in, keys_out, vals_out, n, n_dev,
-                   shift, bits, (const uint32_t*)(t.ghist + pass * 256), t.status[pass], t.ticket + pass, t.err, drop, kept_out);
+                   shift, bits, (const uint32_t*)(t.ghist + pass * 256), t.status[pass], t.ticket + pass, status_word, spin_limit,
+                   drop, kept_out);
     }
     OGS_LAUNCH_CHECK(debug, stream);
     return OGS_OK;

@@ -22,6 +22,8 @@
 // i.e. the geometry / opacity gradients; channels beyond it only receive their own dL/dfeature.  This is
 // what lets ONE fused pass reproduce "RGB loss reaches geometry, ins_feat loss is detached from it"
 // (train.py:431-436) exactly as two separate reference passes would.
+#include <string.h>
+
 #include "ogs_common.h"
 #include "wave_fold.h"
 
@@ -31,6 +33,13 @@ namespace {
 
 constexpr float kAlphaMin = 1.0f / 255.0f;
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+// Timing ablation "run without the gradient atomics" (OGS_BLEND_PREFETCH bits 8 / 9): results are WRONG by construction, so the
+// predicate only exists in a -DOGS_EXPERIMENTS build; the shipped library compiles it to `false`
+#ifdef OGS_EXPERIMENTS
+#define OGS_EXP_SKIP(flag) (flag)
+#else
+#define OGS_EXP_SKIP(flag) false
+#endif
 
 // ---- rank-one part of the reduction on the matrix cores ----------------------------------------------------------
 // The feature (and depth) slots of the gradient record are rank one in (entry, pixel): dL/dfeature_c(i) =
@@ -106,7 +115,7 @@ struct RankOneFold {
             const uint32_t g = (uint32_t)__builtin_amdgcn_ds_bpermute(e * 4, (int)gidv);
             // 32-bit element offset from the (uniform) record array: SGPR-base addressing
             const uint32_t off = g * (uint32_t)GS + (uint32_t)(SLOT0 + m);
-            if (e < cnt && m < NCH && !skip_atomics) atomicAdd(grad_rec + off, (ACC)d[r]);
+            if (e < cnt && m < NCH && !OGS_EXP_SKIP(skip_atomics)) atomicAdd(grad_rec + off, (ACC)d[r]);
         }
         cnt = 0;
     }
@@ -134,56 +143,86 @@ struct RankOneFold {
 // Eight accepted entries per batch.  Rows of the A matrix: entry e owns row rw(e) = 4 (e / 2) + (e % 2) for its blend
 // weights w_e(p) and row rw(e) + 2 for q_e(p) = opacity * G * dL/dalpha; columns of the B matrix: 0..C-1 the upstream
 // feature gradients g_c(p), 9 the upstream depth gradient, 10..15 the moment basis {1, u, v, u^2, uv, v^2} of pixel p
-// about the quadrant centre.  D = A x B (sixteen 16x16x4 MFMAs, K = the quadrant's 64 pixels):
+// about the quadrant centre.  D = A x B (K = the quadrant's 64 pixels):
 //     w rows x columns 0..9   = dL/dfeature_c, dL/ddepth of the entry          (slots 0..9 of the gradient record)
-//     q rows x columns 10..15 = the entry's raw moments M0, Mu, Mv, Muu, Muv, Mvv
+//     q rows x columns 10..15 = the entry's raw moments m0, mu, mv, muu, muv, mvv about the quadrant centre
 // (the other two blocks are computed and dropped: the matrix pipe has the room, the VALU does not).  With this row
 // order D's register r of lane (column n, lane group k) holds row 4 k + r: registers 0, 1 are w rows and 2, 3 are q
-// rows of entries 2 k, 2 k + 1 -- the moment shift runs on two registers only and ONE atomic instruction per register
-// pair adds four entries' complete records (lane group k = entry, lane n = slot).
-//   shift to the Gaussian's centre (a, b) = centre - quadrant centre, d = centre - pixel = (a - u, b - v):
-//     S0 = M0   Sx = a M0 - Mu   Sy = b M0 - Mv   Sxx = a^2 M0 - 2 a Mu + Muu   Sxy = a b M0 - a Mv - b Mu + Muv   Syy = ...
-//   (u, v in {-3.5 .. 3.5}: every basis value is exact in fp32 and no larger than 12.25, so the raw moments carry no
-//   cancellation of their own; the shift has the conditioning of the direct evaluation sum q d^2).
-// LDS: 16 rows x 68 floats per wave (row stride 68 words: 16-byte aligned rows for the ds_read_b128 of the flush, and
-// the sixteen rows of a lane group land in distinct bank groups).  Gaussian id and centre of the batch's entries live
-// in three VGPRs (entry e in lane e: a select per entry); the flush parks them in the rows' spare columns and reads them back
-// per lane group (round 3; six ds_bpermute before: 0.654 -> 0.634 ms.  The same change on RankOneFold's four made the
-// features-only kernel slower, 0.363 -> 0.383 ms, and was not kept).
+// rows of entries 2 k, 2 k + 1 -- ONE atomic instruction per register pair adds four entries' complete records (lane
+// group k = entry, lane n = slot).
+//
+// Round 4, two changes to what follows an accepted entry (0.26 of the kernel's 0.64 ms):
+//  (a) the product runs on the bf16 path, v_mfma_f32_16x16x32_bf16 (16 SIMD cycles per instruction, 8 of them blocking
+//      the vector issue; the exact-fp32 v_mfma_f32_16x16x4_f32 holds it for all of its 32).  Every fp32 operand is split
+//      into two bf16 terms, x = hi + mid + eps: hi = the upper 16 bits of x (truncation: the residual x - hi is exact in
+//      fp32), mid = the residual rounded to nearest bf16, so |eps| <= 2^-16 |x| and unbiased.  All four cross products are
+//      kept (hi.hi, mid.hi, hi.mid, mid.mid; with a truncated hi the last one is up to 2^-14 of the product and cannot be
+//      dropped), accumulated in fp32 from the smallest to the largest: 8 instructions per eight entries instead of 16,
+//      ~128 instead of 512 cycles.  A side: the lane of pixel p stores the two terms of w and of q as 16-bit words into
+//      two planes of the entry's rows (ds_write_b16_d16_hi takes the upper half of a VGPR: the hi term costs no VALU
+//      instruction at all, the mid term and / sub / add); the flush reads one plane of one 32-pixel half of a row with
+//      ONE ds_read_b128 -- eight consecutive pixels = eight K slots, exactly the operand of the instruction.  B side:
+//      loop invariant, split once per kernel into two planes of 8 VGPRs (the 16 VGPRs the fp32 operand took); the moment
+//      basis (values k/4, |.| <= 12.25) is exact in ONE bf16 term.  Product error <= 2^-15 |w g| (q likewise), unbiased:
+//      measured against the float64 oracle in tests/test_10 / test_12 (same 2e-4 bar as before).
+//      OGS_BLEND_FOLD=f32 keeps the exact-fp32 product (alternative-kernel test).
+//  (b) the moments leave the wave about a GLOBAL origin -- the image's pixel (0, 0) -- instead of the Gaussian's own
+//      centre: with X = x0 + u (x0 the quadrant centre) every record slot is  own + cA m0 + cB mu + cC mv  with three
+//      per-LANE constants that do not depend on the entry (slot MX: cA = x0; MXX: cA = x0^2, cB = 2 x0; MXY: cA = x0 y0,
+//      cB = y0, cC = x0; feature slots: zeros) -- three DPP row broadcasts and three fp64 FMAs per register instead of
+//      the per-entry centre stash (two v_writelane per entry, an LDS round trip per flush), thirteen fp32 operations and
+//      six selects.  The shift products need ~36 bits (x0^2 m0), so they are formed in fp64, which the fp64 record and
+//      its atomics take anyway; preprocess_bwd.hip re-centres the six sums on the Gaussian's pixel centre ONCE per
+//      Gaussian, in fp64 (cancellation there: |X|^2 / sigma^2 <= ~1e7 of 1e16).  The fp32 inputs of the shift (the MFMA
+//      results) are the same as before, and so is the conditioning of what comes out.
+// LDS: 16 rows x 68 dwords per wave.  bf16 layout: halfwords [0, 64) = hi plane (pixel = lane), [64, 128) = mid plane,
+// dwords 64..67 spare; fp32 layout: 64 floats + the same spare dwords.  Row stride 68 dwords: 16-byte aligned rows for the
+// ds_read_b128 of the flush, the sixteen rows of a lane group in distinct bank groups.  The Gaussian ids of the batch
+// live in ONE VGPR (entry e in lane e, v_writelane); the flush parks them in the rows' spare dword and each lane group
+// reads the two it owns.
 constexpr int kPairStride = 68;
 struct PairFoldLds {
     float t[16 * kPairStride];
 };
+typedef __bf16 bf16x8_bw __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4_bw __attribute__((ext_vector_type(4)));
 
 template <int N>
 __device__ __forceinline__ float row_bcast(float v) {     // lane n of every row of 16 lanes -> the whole row
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x150 + N, 0xF, 0xF, false));
 }
 
-template <int C, bool DEPTH, int GS, typename ACC>
+// two-term bf16 split of an fp32 value: hi = upper half of x (truncated), mid = upper half of the returned word
+// (the exact residual x - hi, rounded to nearest bf16 by adding half an ulp before the truncating 16-bit store)
+__device__ __forceinline__ uint32_t bf16_mid_word(float x) {
+    const float r = x - __uint_as_float(__float_as_uint(x) & 0xFFFF0000u);
+    return __float_as_uint(r) + 0x8000u;
+}
+
+template <int C, bool DEPTH, bool BF16>
 struct PairFold {
     float* t;
     uint32_t gidv;      // lane e: Gaussian id of staged entry e
-    float mxv, myv;     // lane e: its centre (pixels)
-    float B[16];
-    float x0, y0;       // quadrant centre
+    uint32_t Bw[16];    // BF16: [0..7] hi plane, [8..15] mid plane (two bf16 per dword); fp32: the sixteen B operands
+    double cA, cB, cC;  // this lane's slot: record value = own + cA m0 + cB mu + cC mv   (zeros on the feature slots)
     int cnt;            // wave-uniform: entries staged
-    bool skip_atomics = false;   // timing experiment (OGS_BLEND_PREFETCH bits 8 / 9)
+    bool skip_atomics = false;   // timing experiment (-DOGS_EXPERIMENTS only)
 
     // gcol(n, pixel): upstream gradient of record slot n (feature n, or depth at slot 9) at a pixel of the image
     template <typename F>
     __device__ __forceinline__ void init(PairFoldLds* lds, int lane, int tx, int ty, int wave, int W, int H, F gcol) {
         t = lds->t;
-        gidv = 0u; mxv = 0.f; myv = 0.f;
+        gidv = 0u;
         cnt = 0;
-        x0 = (float)(tx * kTile + (wave & 1) * 8) + 3.5f;
-        y0 = (float)(ty * kTile + (wave >> 1) * 8) + 3.5f;
+        const int qx0 = tx * kTile + (wave & 1) * 8, qy0 = ty * kTile + (wave >> 1) * 8;
+        const double x0 = (double)qx0 + 3.5, y0 = (double)qy0 + 3.5;        // quadrant centre, image pixel coordinates
         const int n = lane & 15, kq = lane >> 4;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int q = 16 * (j >> 2) + 4 * kq + (j & 3);             // pixel of the 8x8 quadrant fed to MFMA j by this lane group
-            const int px = tx * kTile + (wave & 1) * 8 + (q & 7);
-            const int py = ty * kTile + (wave >> 1) * 8 + (q >> 3);
+        cA = n == kSlotMoments + 1 ? x0 : n == kSlotMoments + 2 ? y0 : n == kSlotMoments + 3 ? x0 * x0
+             : n == kSlotMoments + 4 ? x0 * y0 : n == kSlotMoments + 5 ? y0 * y0 : 0.0;
+        cB = n == kSlotMoments + 3 ? 2.0 * x0 : n == kSlotMoments + 4 ? y0 : 0.0;
+        cC = n == kSlotMoments + 4 ? x0 : n == kSlotMoments + 5 ? 2.0 * y0 : 0.0;
+        auto bval = [&](int q) {                                            // B[pixel q of the quadrant][column n]
+            const int px = qx0 + (q & 7), py = qy0 + (q >> 3);
             const float u = (float)(q & 7) - 3.5f, v = (float)(q >> 3) - 3.5f;
             const bool in = px < W && py < H;
             const bool gcolumn = n < C || (DEPTH && n == kSlotDepth);
@@ -194,77 +233,103 @@ struct PairFold {
             b = n == kSlotMoments + 3 ? u * u : b;
             b = n == kSlotMoments + 4 ? u * v : b;
             b = n == kSlotMoments + 5 ? v * v : b;
-            B[j] = b;
+            return b;
+        };
+        if constexpr (BF16) {
+            // instruction (half h): K slot 8 kq + i <-> pixel 32 h + 8 kq + i = row 4 h + kq of the quadrant, column i
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) {
+                    const float b0 = bval(32 * h + 8 * kq + 2 * i2), b1 = bval(32 * h + 8 * kq + 2 * i2 + 1);
+                    Bw[4 * h + i2] = (__float_as_uint(b0) >> 16) | (__float_as_uint(b1) & 0xFFFF0000u);
+                    Bw[8 + 4 * h + i2] = (bf16_mid_word(b0) >> 16) | (bf16_mid_word(b1) & 0xFFFF0000u);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) Bw[j] = __float_as_uint(bval(16 * (j >> 2) + 4 * kq + (j & 3)));   // pixel fed to MFMA j by this lane group
         }
     }
-    __device__ __forceinline__ void flush(ACC* __restrict__ grad_rec, int lane) {
+    __device__ __forceinline__ void flush(double* __restrict__ grad_rec, int lane) {
         const int m = lane & 15, kq = lane >> 4;
-        floatx4 d = {0.f, 0.f, 0.f, 0.f}, d1 = d;
+        floatx4 d = {0.f, 0.f, 0.f, 0.f};
         // rows beyond the staged entries hold stale weights: a row of A only reaches the same row of D, which is
         // never written out
+        if constexpr (BF16) {
+            const u32x4_bw* rowp = reinterpret_cast<const u32x4_bw*>(t + m * kPairStride);       // 16-byte units of row m
+            const u32x4_bw ah0 = rowp[kq], ah1 = rowp[4 + kq], am0 = rowp[8 + kq], am1 = rowp[12 + kq];
+            const u32x4_bw bh0 = {Bw[0], Bw[1], Bw[2], Bw[3]}, bh1 = {Bw[4], Bw[5], Bw[6], Bw[7]};
+            const u32x4_bw bm0 = {Bw[8], Bw[9], Bw[10], Bw[11]}, bm1 = {Bw[12], Bw[13], Bw[14], Bw[15]};
+            auto mm = [](const u32x4_bw& a, const u32x4_bw& b, floatx4 c) {
+                return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_bw, a), __builtin_bit_cast(bf16x8_bw, b), c, 0, 0, 0);
+            };
+            d = mm(am0, bm0, d); d = mm(am1, bm1, d);        // mid x mid  (<= 2^-14 of the product)
+            d = mm(am0, bh0, d); d = mm(am1, bh1, d);        // mid x hi
+            d = mm(ah0, bm0, d); d = mm(ah1, bm1, d);        // hi  x mid
+            d = mm(ah0, bh0, d); d = mm(ah1, bh1, d);        // hi  x hi
+        } else {
+            floatx4 d1 = d;
 #pragma unroll
-        for (int J = 0; J < 4; ++J) {
-            const float4 a = *reinterpret_cast<const float4*>(t + m * kPairStride + 16 * J + 4 * kq);
-            d = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, B[4 * J], d, 0, 0, 0);
-            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, B[4 * J + 1], d1, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, B[4 * J + 2], d, 0, 0, 0);
-            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, B[4 * J + 3], d1, 0, 0, 0);
+            for (int J = 0; J < 4; ++J) {
+                const float4 a = *reinterpret_cast<const float4*>(t + m * kPairStride + 16 * J + 4 * kq);
+                d = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, __uint_as_float(Bw[4 * J]), d, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, __uint_as_float(Bw[4 * J + 1]), d1, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, __uint_as_float(Bw[4 * J + 2]), d, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, __uint_as_float(Bw[4 * J + 3]), d1, 0, 0, 0);
+            }
+            d = d + d1;
         }
-        d = d + d1;
         const bool column_used = m < C || (DEPTH && m == kSlotDepth) || m >= kSlotMoments;
-        // id and centre of the batch's eight entries: lane e of the three stash registers -> the spare columns 64..66 of row e
-        // -> each lane group reads the two entries it owns (one masked 12-byte write + two 16-byte reads instead of six
-        // ds_bpermute at 24 issue cycles each: 144 of the ~900 cycles of a flush)
-        if (lane < 8) {
-            float* sp = t + lane * kPairStride + 64;
-            sp[0] = __uint_as_float(gidv); sp[1] = mxv; sp[2] = myv;
-        }
+        // ids of the batch's eight entries: lane e of the stash register -> the spare dword 64 of row e -> each lane group
+        // reads the two it owns
+        if (lane < 8) t[lane * kPairStride + 64] = __uint_as_float(gidv);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
             const int e = 2 * kq + rr;
-            const float4 sd = *reinterpret_cast<const float4*>(t + e * kPairStride + 64);
-            const uint32_t g = __float_as_uint(sd.x);
-            const float a = sd.y - x0;
-            const float b = sd.z - y0;
+            const uint32_t g = __float_as_uint(t[e * kPairStride + 64]);
             const float own = d[2 + rr];
-            const float M0 = row_bcast<kSlotMoments>(own), Mu = row_bcast<kSlotMoments + 1>(own),
-                        Mv = row_bcast<kSlotMoments + 2>(own);
-            const float ta = a * M0, tb = b * M0;
-            float val = own;                                                        // S0
-            val = m == kSlotMoments + 1 ? ta - own : val;                           // Sx
-            val = m == kSlotMoments + 2 ? tb - own : val;                           // Sy
-            val = m == kSlotMoments + 3 ? own + a * (ta - 2.f * Mu) : val;          // Sxx
-            val = m == kSlotMoments + 4 ? (own + a * (tb - Mv)) - b * Mu : val;     // Sxy
-            val = m == kSlotMoments + 5 ? own + b * (tb - 2.f * Mv) : val;          // Syy
-            val = m < kSlotMoments ? d[rr] : val;                                   // feature / depth slots
-            // 32-bit element offset from the (uniform) record array: SGPR-base addressing, no 64-bit vector arithmetic (P < 2^28)
-            const uint32_t off = g * (uint32_t)GS + (uint32_t)m;
-            if (e < cnt && column_used && !skip_atomics) atomicAdd(grad_rec + off, (ACC)val);
+            const float m0 = row_bcast<kSlotMoments>(own), mu = row_bcast<kSlotMoments + 1>(own),
+                        mv = row_bcast<kSlotMoments + 2>(own);
+            double val = (double)(m < kSlotMoments ? d[rr] : own);          // feature / depth slots: the w row, constants zero
+            val = fma(cA, (double)m0, val);
+            val = fma(cB, (double)mu, val);
+            val = fma(cC, (double)mv, val);
+            // 32-bit element offset from the (uniform) record array: SGPR-base addressing, no 64-bit vector arithmetic
+            // (P * 16 < 2^32: checked in ogs_raster_backward)
+            const uint32_t off = g * 16u + (uint32_t)m;
+            if (e < cnt && column_used && !OGS_EXP_SKIP(skip_atomics)) atomicAdd(grad_rec + off, val);
         }
         cnt = 0;
     }
-    // one accepted entry: this lane's blend weight and q, the entry's Gaussian id and centre (wave-uniform)
-    __device__ __forceinline__ void push(float wl, float ql, uint32_t g, float mx, float my, ACC* __restrict__ grad_rec,
-                                         int lane) {
-        float* row = t + (((cnt >> 1) << 2) | (cnt & 1)) * kPairStride;
-        row[lane] = wl;
-        row[2 * kPairStride + lane] = ql;
-        // lane cnt of the three stash registers <- wave-uniform values: v_writelane_b32, one instruction each (a select
-        // costs a move of the scalar into a VGPR plus a v_cndmask).  Two different SGPRs in one VOP3 exceed the constant
-        // bus, so the lane select travels in M0 (saved and restored: M0 is the compiler's)
+    // one accepted entry: this lane's blend weight and q, the entry's Gaussian id (wave-uniform)
+    __device__ __forceinline__ void push(float wl, float ql, uint32_t g, double* __restrict__ grad_rec, int lane) {
+        const int rw = ((cnt >> 1) << 2) | (cnt & 1);
+        if constexpr (BF16) {
+            uint16_t* row = reinterpret_cast<uint16_t*>(t + rw * kPairStride);
+            row[lane] = (uint16_t)(__float_as_uint(wl) >> 16);
+            row[64 + lane] = (uint16_t)(bf16_mid_word(wl) >> 16);
+            row[4 * kPairStride + lane] = (uint16_t)(__float_as_uint(ql) >> 16);          // two rows below (halfword units)
+            row[4 * kPairStride + 64 + lane] = (uint16_t)(bf16_mid_word(ql) >> 16);
+        } else {
+            float* row = t + rw * kPairStride;
+            row[lane] = wl;
+            row[2 * kPairStride + lane] = ql;
+        }
+        // lane cnt of the stash register <- the wave-uniform id: v_writelane_b32, one instruction (a select costs a move of
+        // the scalar into a VGPR plus a v_cndmask).  Two different SGPRs in one VOP3 exceed the constant bus, so the lane
+        // select travels in M0 (saved and restored: M0 is the compiler's)
         uint32_t m0_saved;
         asm volatile(
-            "s_mov_b32 %3, m0\n\t"
-            "s_mov_b32 m0, %7\n\t"
+            "s_mov_b32 %1, m0\n\t"
+            "s_mov_b32 m0, %3\n\t"
             "s_nop 0\n\t"                       // inline asm is opaque to the hazard recognizer: one wait state after the M0 write
-            "v_writelane_b32 %0, %4, m0\n\t"
-            "v_writelane_b32 %1, %5, m0\n\t"
-            "v_writelane_b32 %2, %6, m0\n\t"
-            "s_mov_b32 m0, %3"
-            : "+v"(gidv), "+v"(mxv), "+v"(myv), "=&s"(m0_saved)
-            : "s"(g), "s"(mx), "s"(my), "s"(cnt));
+            "v_writelane_b32 %0, %2, m0\n\t"
+            "s_mov_b32 m0, %1"
+            : "+v"(gidv), "=&s"(m0_saved)
+            : "s"(g), "s"(cnt));
         ++cnt;
         if (cnt == 8) flush(grad_rec, lane);
     }
@@ -280,15 +345,14 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 // features): a runtime value turned every per-channel update into v_cndmask selects and kept dead math alive.
 // DEPTH = false: no gradient arrives through the depth image (dL_ddepth == NULL -- every loss of the reference,
 // gaussian_renderer/__init__.py:362 "not used"): the depth recursion and its dL/dalpha term are compiled out.
-template <int C, int GC, bool DEPTH, typename ACC>
+template <int C, int GC, bool DEPTH, bool BF16>
 __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     const uint2* __restrict__ ranges, const float* __restrict__ stream, const uint32_t* __restrict__ quad_list, int W,
     int H, int gx, int tiles, const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const uint32_t* __restrict__ qcount, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha_map,
-    ACC* __restrict__ grad_rec, int pf_lines, const uint32_t* __restrict__ tile_order) {
+    double* __restrict__ grad_rec, int pf_lines, const uint32_t* __restrict__ tile_order) {
     constexpr int RS = stream_vec4(C) * 4;
-    constexpr int GS = grad_stride(C);
-    static_assert(C + 7 <= 16, "gradient record must fit 16 slots");
+    static_assert(C + 7 <= 16 && grad_stride(C) == 16, "gradient record must fit 16 slots");
     __shared__ PairFoldLds s_fold[kBlock / kWave];
 
     const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;                // virtual tile (grouped pass): image * tiles + tile in the image
@@ -330,7 +394,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     const float gd = (DEPTH && inside) ? dL_ddepth[pix] : 0.f;
     const float ga = (inside && dL_dalpha_map) ? dL_dalpha_map[pix] : 0.f;
     // every slot of the gradient record is reduced over the quadrant's pixels on the matrix cores (PairFold)
-    PairFold<C, DEPTH, GS, ACC> fold;
+    PairFold<C, DEPTH, BF16> fold;
     fold.skip_atomics = (pf_lines & 0x300) != 0;
     const float* __restrict__ ddepth_img = DEPTH ? dL_ddepth + (size_t)img * plane : nullptr;
     fold.init(&s_fold[wave], lane, tx, ty, wave, W, H, [&](int n, size_t p) {
@@ -395,7 +459,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
             // every geometry partial carries the common factor q = opacity * G * dL/dalpha (G = 0 on idle lanes) times a
             // polynomial of the pixel offset: the fold takes q's pixel moments, preprocess_bwd.hip does the rest
             const float q = opac * (G * dL_dalpha);
-            fold.push(w, q, __float_as_uint(cur[7]), cur[0], cur[1], grad_rec, lane);
+            fold.push(w, q, __float_as_uint(cur[7]), grad_rec, lane);
         }
     };
     // back-to-front over the quadrant's index stream (see blend_fwd.hip); reads below index 0 land in the previous
@@ -445,279 +509,6 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
         }
     }
     if (fold.cnt > 0) fold.flush(grad_rec, lane);
-    pf.retire(reinterpret_cast<uint32_t*>(grad_rec), W);
-}
-
-// ---- full backward, one list per 4x4 pixel block (round 3) ----------------------------------------------------------
-// Same idea as blend_forward_rows_kernel (blend_fwd.hip): a wave owns a quadrant and walks the quadrant's index stream
-// back to front in CHUNKS of 32 entries; lane e gathers and parks record e in LDS, an exact 4x4-block reach test splits the
-// chunk into four lists, and the four DPP rows of the wave -- row r = the 16 pixels of block r -- walk their lists side by
-// side with every operand of the per-pixel arithmetic in VGPRs (the quadrant walk pays 4 issue cycles for almost every
-// instruction because the record sits in SGPRs, and keeps ~51 % of its lanes busy).
-// Reduction: a chunk is worked off in four WINDOWS of eight slots.  Inside a window every row walks ITS entries of those
-// eight slots (lockstep; a row that has fewer reads the dummy record) and leaves its blend weight w and its
-// q = opacity * G * dL/dalpha in the A tile of PairFold -- in the row of the SLOT, at the columns of its own 16 pixels.  Rows
-// never share a column, so after the window the tile holds, per slot, w and q over all 64 pixels of the quadrant (zero where
-// a block was not reached: the tile is cleared per window), and the window ends exactly like a batch of the quadrant
-// kernel: sixteen v_mfma_f32_16x16x4_f32 (K = 64 pixels), the moment shift, one atomic instruction per four slots.  Same
-// atomic traffic as the quadrant kernel (one record per (entry, quadrant)); the per-(pixel, entry) arithmetic is
-// blend_backward_kernel's, in the same order.  LDS per wave: tile 4.25 KB + parked records 1.5 KB + lists 0.5 KB.
-template <int NP4>
-struct RowsBwdLds {
-    static constexpr int kChunk = 32;
-    float t[16 * kPairStride];          // PairFold's A tile: row rw(e') (+2 for q), column = pixel of the quadrant
-    float4 rec[(kChunk + 1) * NP4];     // parked records (+ dummy slot kChunk)
-    uint32_t list[4][kChunk / 8][8];    // per row and window: chunk slots that can reach the block, padded with the dummy
-};
-
-template <int C, int GC, bool DEPTH, typename ACC>
-__global__ __launch_bounds__(kBlock) void blend_backward_rows_kernel(
-    const uint2* __restrict__ ranges, const float* __restrict__ stream, const uint32_t* __restrict__ quad_list, int W,
-    int H, int gx, int tiles, const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-    const uint32_t* __restrict__ qcount, const float* __restrict__ dL_dcolor, const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dalpha_map,
-    ACC* __restrict__ grad_rec, int pf_lines, const uint32_t* __restrict__ tile_order) {
-    constexpr int NV4 = stream_vec4(C);
-    constexpr int RS = NV4 * 4;
-    constexpr int GS = grad_stride(C);
-    constexpr int NP4 = DEPTH ? NV4 : (8 + GC + 3) / 4;           // float4s of a record this loop touches
-    constexpr int kChunk = RowsBwdLds<NP4>::kChunk;
-    static_assert(C + 7 <= 16, "gradient record must fit 16 slots");
-    __shared__ RowsBwdLds<NP4> s_lds[kBlock / kWave];
-
-    const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
-    const int img = tile / tiles, timg = tile - img * tiles;
-    const int tx = timg % gx, ty = timg / gx;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int row = lane >> 4, l16 = lane & 15;
-    const int qx0 = tx * kTile + (wave & 1) * 8, qy0 = ty * kTile + (wave >> 1) * 8;
-    const int bxq = 4 * (row & 1) + (l16 & 3), byq = 4 * (row >> 1) + (l16 >> 2);     // this lane's pixel inside the quadrant
-    const int px = qx0 + bxq, py = qy0 + byq;
-    const int qcol = byq * 8 + bxq;                                                    // its column of the A tile
-    const bool inside = px < W && py < H;
-    const float fx = (float)px, fy = (float)py;
-    const size_t plane = (size_t)W * H;
-    const size_t pix = (size_t)img * plane + (size_t)py * W + px;
-    dL_dcolor += (size_t)img * (C - 1) * plane;
-    const float* __restrict__ dcol_img = dL_dcolor + (size_t)img * plane;
-
-    const uint2 range = ranges[tile];
-    const int last_contrib = inside ? (int)n_contrib[pix] : 0;
-    const int hi = __builtin_amdgcn_readfirstlane(wave_max_i32(last_contrib));
-    if (hi == 0) return;
-    const int n_tile = (int)(range.y - range.x);
-    const float* __restrict__ tb = stream + (size_t)range.x * RS;
-    const uint32_t* __restrict__ qi = quad_list + ((size_t)range.x * 5 + (size_t)wave * n_tile);
-    const int n_kept = (int)qcount[tile * 5 + 4];
-    const uint32_t lim = n_kept > 0 ? (uint32_t)n_kept - 1u : 0u;
-    RecordPrefetch pf;
-    pf.issue(tb, n_kept, RS, tid, pf_lines & 0xFF);
-    const bool skip_atomics = (pf_lines & 0x300) != 0;
-
-    RowsBwdLds<NP4>& L = s_lds[wave];
-    const float T_final = inside ? final_T[pix] : 0.f;
-    float T = T_final;
-    float g[GC];
-    float bg_dot = 0.f;
-#pragma unroll
-    for (int c = 0; c < GC; ++c) {
-        g[c] = inside ? dL_dcolor[c * plane + pix] : 0.f;
-        bg_dot += bg[c] * g[c];
-    }
-    const float gd = (DEPTH && inside) ? dL_ddepth[pix] : 0.f;
-    const float ga = (inside && dL_dalpha_map) ? dL_dalpha_map[pix] : 0.f;
-    float R[GC];
-#pragma unroll
-    for (int c = 0; c < GC; ++c) R[c] = 0.f;
-    float Rd = 0.f, Ra = 0.f;
-    const float tf_bg = T_final * bg_dot;
-    // B matrix of PairFold: lane (column n, group kq) feeds MFMA j with the quadrant pixel q = 16 (j >> 2) + 4 kq + (j & 3)
-    const int n = l16, kq = row;
-    float Bm[16];
-    const float* __restrict__ ddepth_img = DEPTH ? dL_ddepth + (size_t)img * plane : nullptr;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int q = 16 * (j >> 2) + 4 * kq + (j & 3);
-        const int ppx = qx0 + (q & 7), ppy = qy0 + (q >> 3);
-        const float u = (float)(q & 7) - 3.5f, v = (float)(q >> 3) - 3.5f;
-        const bool in = ppx < W && ppy < H;
-        const bool gcolumn = n < C || (DEPTH && n == kSlotDepth);
-        float b = 0.f;
-        if (in && gcolumn) b = (DEPTH && n == kSlotDepth) ? ddepth_img[(size_t)ppy * W + ppx] : dcol_img[(size_t)n * plane + (size_t)ppy * W + ppx];
-        b = n == kSlotMoments ? 1.f : b;
-        b = n == kSlotMoments + 1 ? u : b;
-        b = n == kSlotMoments + 2 ? v : b;
-        b = n == kSlotMoments + 3 ? u * u : b;
-        b = n == kSlotMoments + 4 ? u * v : b;
-        b = n == kSlotMoments + 5 ? v * v : b;
-        Bm[j] = b;
-    }
-    const float x0 = (float)qx0 + 3.5f, y0 = (float)qy0 + 3.5f;           // quadrant centre (moment origin)
-    const bool column_used = n < C || (DEPTH && n == kSlotDepth) || n >= kSlotMoments;
-    if (lane == 0) {                          // dummy record: h < 0 -> never a candidate
-#pragma unroll
-        for (int k = 0; k < NP4; ++k) L.rec[kChunk * NP4 + k] = float4{0.f, 0.f, 0.f, 0.f};
-        L.rec[kChunk * NP4 + 1] = float4{0.f, -1.f, 0.f, 0.f};
-    }
-
-    // one (pixel, entry): blend_backward_kernel's arithmetic; leaves w and q in the A-tile rows of window slot ew
-    auto consume = [&](const float4 (&rv)[NP4], int ew, int idx) {
-        auto at = [&](int i) { const float4 q4 = rv[i >> 2]; return (i & 3) == 0 ? q4.x : (i & 3) == 1 ? q4.y : (i & 3) == 2 ? q4.z : q4.w; };
-        const float dx = at(0) - fx, dy = at(1) - fy;
-        const float power = blend_power(at(2), at(3), at(4), dx, dy);
-        const float hh = at(5);
-        const bool near = fabsf(power + hh) <= hh, reached = idx < last_contrib;
-        const bool cand = near && reached;
-        const uint64_t cand_mask = __ballot(near) & __ballot(reached);
-        if (cand_mask == 0ull) return;
-        const float opac = at(6);
-        const float Graw = __expf(power);
-        const float alpha = fminf(0.99f, opac * Graw);
-        const bool act = cand && alpha >= kAlphaMin;
-        if ((__ballot(alpha >= kAlphaMin) & cand_mask) != 0ull) {
-            const float al = act ? alpha : 0.f;
-            const float G = act ? Graw : 0.f;
-            const float inv = __builtin_amdgcn_rcpf(1.0f - al);
-            T = T * inv;
-            const float w = al * T;
-            float dL_dalpha = 0.f;
-#pragma unroll
-            for (int c = 0; c < GC; ++c) {
-                const float diff = at(8 + c) - R[c];
-                dL_dalpha += diff * g[c];
-                R[c] += al * diff;
-            }
-            if constexpr (DEPTH) {
-                const float diff = at(8 + C) - Rd;
-                dL_dalpha += diff * gd;
-                Rd += al * diff;
-            }
-            {
-                const float diff = 1.0f - Ra;
-                dL_dalpha += diff * ga;
-                Ra += al * diff;
-            }
-            dL_dalpha = dL_dalpha * T - inv * tf_bg;
-            const float q = opac * (G * dL_dalpha);
-            // rows of window slot ew (PairFold's order: w in row 4 (ew / 2) + (ew % 2), q two rows below), this pixel's column.
-            // A dummy step (ew = 8) is no candidate anywhere: it never gets here with act, and its w = q = 0 go nowhere
-            if (act) {
-                float* cell = &L.t[(((ew >> 1) << 2) | (ew & 1)) * kPairStride + qcol];
-                cell[0] = w;
-                cell[2 * kPairStride] = q;
-            }
-        }
-    };
-
-    // back to front over the quadrant stream, kChunk positions at a time: chunk slot e <-> position top - e
-    for (int top = hi - 1; top >= 0; top -= kChunk) {
-        // ---- 1. gather + park (lanes 0..31); reach test: lane (e, half) tests blocks 2 half, 2 half + 1 ----
-        const int e = lane & (kChunk - 1), half = lane >> 5;
-        const int pos = top - e;
-        const bool have = pos >= 0;
-        const uint32_t ridx = have ? min(qi[pos], lim) : 0u;
-        const float4* __restrict__ rp = reinterpret_cast<const float4*>(tb + (size_t)ridx * RS);
-        float4 rg[NP4];
-#pragma unroll
-        for (int k = 0; k < NP4; ++k) rg[k] = rp[k];
-        if (half == 0) {
-#pragma unroll
-            for (int k = 0; k < NP4; ++k) L.rec[e * NP4 + k] = rg[k];
-        }
-        bool reach2[2];
-        {
-            const float gxp = rg[0].x, gyp = rg[0].y;
-            const float A = -2.f * rg[0].z, B = -rg[0].w, Cc = -2.f * rg[1].x, thr = -2.f * rg[1].y;
-            const float nbA = -B / A, nbC = -B / Cc;
-#pragma unroll
-            for (int bb = 0; bb < 2; ++bb) {
-                const int b = 2 * half + bb;
-                const float ox = (float)(qx0 + 4 * (b & 1)), oy = (float)(qy0 + 4 * (b >> 1));
-                const float m = max_power_in_box(A, B, Cc, nbA, nbC, gxp - ox - 3.f, gxp - ox, gyp - oy - 3.f, gyp - oy);
-                reach2[bb] = have && m >= thr;
-            }
-        }
-        // ---- 2. per row and window: compacted slot lists, padded with the dummy ----
-        {
-            uint32_t* flat = &L.list[0][0][0];
-            flat[lane] = (uint32_t)kChunk;
-            flat[lane + kWave] = (uint32_t)kChunk;
-        }
-        uint32_t mask_b[4];
-#pragma unroll
-        for (int bb = 0; bb < 2; ++bb) {
-            const uint64_t m64 = __ballot(reach2[bb]);
-            mask_b[bb] = (uint32_t)m64;                 // block bb     (lanes of half 0)
-            mask_b[2 + bb] = (uint32_t)(m64 >> 32);     // block 2 + bb (lanes of half 1)
-            const uint32_t mine = half == 0 ? (uint32_t)m64 : (uint32_t)(m64 >> 32);
-            const uint32_t win = (mine >> (e & ~7)) & 0xFFu;                       // this slot's window
-            const int posw = __popc(win & ((1u << (e & 7)) - 1u));
-            if (reach2[bb]) L.list[2 * half + bb][e >> 3][posw] = (uint32_t)e;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // ---- 3. four windows of eight slots ----
-#pragma unroll 1
-        for (int w = 0; w < kChunk / 8; ++w) {
-            const uint32_t any = ((mask_b[0] | mask_b[1] | mask_b[2] | mask_b[3]) >> (8 * w)) & 0xFFu;    // slots some block reaches
-            if (any == 0u) continue;
-            int nsteps = 0;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) nsteps = max(nsteps, (int)__popc((mask_b[b] >> (8 * w)) & 0xFFu));
-            // clear the A tile (16 rows x 64 columns; the row stride leaves the pad columns alone)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int cell = (lane + k * kWave) * 4;                 // float4 cells 0..255 -> row = cell / 64, column = cell % 64
-                *reinterpret_cast<float4*>(&L.t[(cell >> 6) * kPairStride + (cell & 63)]) = float4{0.f, 0.f, 0.f, 0.f};
-            }
-            const uint32_t* __restrict__ mylist = L.list[row][w];
-            float4 ra[NP4], rb[NP4];
-            uint32_t e0 = mylist[0], e1 = mylist[1];
-#pragma unroll
-            for (int k = 0; k < NP4; ++k) ra[k] = L.rec[e0 * NP4 + k];
-            for (int t = 0; t < nsteps; t += 2) {
-                const uint32_t e2 = mylist[(t + 2) & 7], e3 = mylist[(t + 3) & 7];
-#pragma unroll
-                for (int k = 0; k < NP4; ++k) rb[k] = L.rec[e1 * NP4 + k];
-                consume(ra, (int)e0 - 8 * w, top - (int)e0);
-#pragma unroll
-                for (int k = 0; k < NP4; ++k) ra[k] = L.rec[e2 * NP4 + k];
-                if (t + 1 < nsteps) consume(rb, (int)e1 - 8 * w, top - (int)e1);
-                e0 = e2; e1 = e3;
-            }
-            // ---- window flush: PairFold::flush on the eight slots of the window ----
-            floatx4 d = {0.f, 0.f, 0.f, 0.f}, d1 = d;
-#pragma unroll
-            for (int J = 0; J < 4; ++J) {
-                const float4 a = *reinterpret_cast<const float4*>(&L.t[n * kPairStride + 16 * J + 4 * kq]);
-                d = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, Bm[4 * J], d, 0, 0, 0);
-                d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, Bm[4 * J + 1], d1, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, Bm[4 * J + 2], d, 0, 0, 0);
-                d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, Bm[4 * J + 3], d1, 0, 0, 0);
-            }
-            d = d + d1;
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                const int ew = 2 * kq + rr;                                   // window slot of this register pair
-                const int slot = 8 * w + ew;
-                const float4 gv = L.rec[slot * NP4], g2 = L.rec[slot * NP4 + 1];
-                const uint32_t gid = __float_as_uint(g2.w);
-                const float a = gv.x - x0, b = gv.y - y0;
-                const float own = d[2 + rr];
-                const float M0 = row_bcast<kSlotMoments>(own), Mu = row_bcast<kSlotMoments + 1>(own), Mv = row_bcast<kSlotMoments + 2>(own);
-                const float ta = a * M0, tbb = b * M0;
-                float val = own;                                                        // S0
-                val = n == kSlotMoments + 1 ? ta - own : val;                           // Sx
-                val = n == kSlotMoments + 2 ? tbb - own : val;                          // Sy
-                val = n == kSlotMoments + 3 ? own + a * (ta - 2.f * Mu) : val;          // Sxx
-                val = n == kSlotMoments + 4 ? (own + a * (tbb - Mv)) - b * Mu : val;    // Sxy
-                val = n == kSlotMoments + 5 ? own + b * (tbb - 2.f * Mv) : val;         // Syy
-                val = n < kSlotMoments ? d[rr] : val;                                   // feature / depth slots
-                if (((any >> ew) & 1u) != 0u && column_used && !skip_atomics) atomicAdd(grad_rec + ((size_t)gid * GS + n), (ACC)val);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
     pf.retire(reinterpret_cast<uint32_t*>(grad_rec), W);
 }
 
@@ -913,14 +704,14 @@ static bool feat_lds_enabled() {
     return v;
 }
 
-// OGS_BLEND_ROWS_BWD=1: the per-4x4-block full backward (blend_backward_rows_kernel); default: the quadrant walk
-static bool backward_rows_enabled() {
-    static const bool v = [] { const char* e = getenv("OGS_BLEND_ROWS_BWD"); return e && atoi(e) != 0; }();
+static bool fold_bf16_enabled() {
+    static const bool v = [] { const char* e = getenv("OGS_BLEND_FOLD"); return !(e && strcmp(e, "f32") == 0); }();
     return v;
 }
 
-template <int C, typename ACC>
+template <int C>
 int launch_c(const OgsRasterBwdArgs& a, const ImageState& is, void* grad_rec_, hipStream_t s) {
+    using ACC = double;          // the gradient record is 16 fp64 running sums (ogs_common.h); round 3's fp32 record is gone
     ACC* grad_rec = static_cast<ACC*>(grad_rec_);
     const int gx = (a.W + kTile - 1) / kTile, gy = (a.H + kTile - 1) / kTile;
     static constexpr const char* const kNames[4] = {"blend_backward_kernel<3>", "blend_backward_kernel<6>",
@@ -954,17 +745,17 @@ int launch_c(const OgsRasterBwdArgs& a, const ImageState& is, void* grad_rec_, h
         OGS_LAUNCH_CHECK(a.debug, s);
         return OGS_OK;
     }
-    static constexpr const char* const kRowNames[4] = {"blend_backward_rows_kernel<3>", "blend_backward_rows_kernel<6>",
-                                                       "blend_backward_rows_kernel<9>", "blend_backward_rows_kernel<12>"};
-    const bool rows = backward_rows_enabled();
+    // the fold's product: two-term bf16 split on v_mfma_f32_16x16x32_bf16 (default) or, OGS_BLEND_FOLD=f32, exact fp32 on
+    // v_mfma_f32_16x16x4_f32 (round 2 / 3; kept for the alternative-kernel parity test and A-B timing)
+    const bool bf16 = fold_bf16_enabled();
 #define OGS_BWD_LAUNCH(GCV, DEPTHV)                                                                                  \
-    if (rows)                                                                                                        \
-        OGS_LAUNCH_NAMED(chan_name<C>(kRowNames), (blend_backward_rows_kernel<C, GCV, DEPTHV, ACC>), dim3(vtiles), dim3(kBlock), 0, s, \
+    if (bf16)                                                                                                        \
+    OGS_LAUNCH_NAMED(chan_name<C>(kNames), (blend_backward_kernel<C, GCV, DEPTHV, true>), dim3(vtiles), dim3(kBlock), 0, s, \
                      (const uint2*)is.ranges, stream, quads, a.W, a.H, gx, gx * gy, a.bg, (const float*)is.final_T,                  \
                      (const uint32_t*)is.n_contrib, (const uint32_t*)is.qcount, a.dL_dcolor, a.dL_ddepth, a.dL_dalpha, grad_rec,  \
                      blend_prefetch_lines(), order);                                                                 \
     else                                                                                                             \
-    OGS_LAUNCH_NAMED(chan_name<C>(kNames), (blend_backward_kernel<C, GCV, DEPTHV, ACC>), dim3(vtiles), dim3(kBlock), 0, s, \
+    OGS_LAUNCH_NAMED(chan_name<C>(kNames), (blend_backward_kernel<C, GCV, DEPTHV, false>), dim3(vtiles), dim3(kBlock), 0, s, \
                      (const uint2*)is.ranges, stream, quads, a.W, a.H, gx, gx * gy, a.bg, (const float*)is.final_T,                  \
                      (const uint32_t*)is.n_contrib, (const uint32_t*)is.qcount, a.dL_dcolor, a.dL_ddepth, a.dL_dalpha, grad_rec,  \
                      blend_prefetch_lines(), order)
@@ -982,21 +773,16 @@ int launch_c(const OgsRasterBwdArgs& a, const ImageState& is, void* grad_rec_, h
     return OGS_OK;
 }
 
-template <typename ACC>
-int launch_acc(const OgsRasterBwdArgs& a, const ImageState& is, void* grad_rec, hipStream_t s) {
-    switch (a.C) {
-        case 3: return launch_c<3, ACC>(a, is, grad_rec, s);
-        case 6: return launch_c<6, ACC>(a, is, grad_rec, s);
-        case 9: return launch_c<9, ACC>(a, is, grad_rec, s);
-        default: set_error("backward: unsupported channel count C=%d (3, 6 or 9)", a.C); return OGS_ERR_UNSUPPORTED;
-    }
-}
-
 }  // namespace
 
-int launch_blend_backward(const OgsRasterBwdArgs& a, const ImageState& is, void* grad_rec, bool f64, hipStream_t s) {
+int launch_blend_backward(const OgsRasterBwdArgs& a, const ImageState& is, void* grad_rec, hipStream_t s) {
     if (a.num_rendered <= 0) return OGS_OK;
-    return f64 ? launch_acc<double>(a, is, grad_rec, s) : launch_acc<float>(a, is, grad_rec, s);
+    switch (a.C) {
+        case 3: return launch_c<3>(a, is, grad_rec, s);
+        case 6: return launch_c<6>(a, is, grad_rec, s);
+        case 9: return launch_c<9>(a, is, grad_rec, s);
+        default: set_error("backward: unsupported channel count C=%d (3, 6 or 9)", a.C); return OGS_ERR_UNSUPPORTED;
+    }
 }
 
 int launch_wave_fold16_test(const float* in, float* out, hipStream_t s) {

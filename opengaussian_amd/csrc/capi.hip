@@ -54,13 +54,37 @@ ProfScope::~ProfScope() {
     (void)hipEventRecord(g_prof[slot].stop, stream);
 }
 
-// OGS_GRAD_ACCUM=f32 selects the fp32 gradient record (diagnostics / A-B timing); default fp64 (ogs_common.h)
-static bool grad_accum_f64() {
-    static const bool v = [] {
-        const char* e = getenv("OGS_GRAD_ACCUM");
-        return !(e && strcmp(e, "f32") == 0);
-    }();
-    return v;
+// ---- sticky asynchronous device status (ogs_common.h) -----------------------------------------------------------------
+namespace {
+uint32_t* g_async_status = nullptr;      // pinned, device-mapped; never freed (process lifetime)
+std::mutex g_async_mu;
+}  // namespace
+uint32_t* async_status_word() {
+    std::lock_guard<std::mutex> lk(g_async_mu);
+    if (!g_async_status) {
+        void* p = nullptr;
+        const hipError_t e = hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocPortable);
+        if (e != hipSuccess || !p) {
+            set_error("hipHostMalloc of the async status word failed: %s", hipGetErrorString(e));
+            return nullptr;
+        }
+        memset(p, 0, 64);
+        g_async_status = static_cast<uint32_t*>(p);
+    }
+    return g_async_status;
+}
+int take_async_status() {
+    std::lock_guard<std::mutex> lk(g_async_mu);
+    if (!g_async_status) return 0;
+    return (int)__atomic_exchange_n(g_async_status, 0u, __ATOMIC_ACQ_REL);
+}
+int check_async_status(const char* where) {
+    const int st = take_async_status();
+    if (st == 0) return OGS_OK;
+    set_error("%s: a kernel of an earlier launch reported status 0x%x%s -- the results of the passes since the last check "
+              "are not valid", where, st,
+              (st & (int)kAsyncRadixSpin) ? " (one-launch radix pass: a look-back wait exceeded its bound)" : "");
+    return OGS_ERR_DEVICE;
 }
 
 }  // namespace ogs (reopened below)
@@ -69,7 +93,12 @@ int ogs::blend_prefetch_lines() {
         const char* e = getenv("OGS_BLEND_PREFETCH");
         const int n = e ? atoi(e) : kPrefetchMax;
         const int lines = (n & 0xFF) > kPrefetchMax ? kPrefetchMax : (n & 0xFF);
-        return n < 0 ? 0 : (lines | (n & 0x300));        // bits 8 / 9: timing experiments only (skip the feature / geometry atomics)
+#ifdef OGS_EXPERIMENTS
+        return n < 0 ? 0 : (lines | (n & 0x300));        // bits 8 / 9: timing ablations (skip the feature / geometry atomics):
+                                                         // WRONG gradients by construction, compiled in only with -DOGS_EXPERIMENTS
+#else
+        return n < 0 ? 0 : lines;                        // the shipped library has no switch that changes a result
+#endif
     }();
     return v;
 }
@@ -120,7 +149,9 @@ using namespace ogs;
 
 extern "C" {
 
-int ogs_version(void) { return 301; }
+int ogs_version(void) { return 400; }
+
+int ogs_check_async_status(void) { return check_async_status("ogs_check_async_status"); }
 
 /* Per-kernel timing with HIP events recorded on the launch stream (bench.py's `roofline` leg).
  * ogs_prof_enable(1) starts a fresh recording; ogs_prof_collect() waits for the recorded events and
@@ -190,6 +221,8 @@ int ogs_raster_forward_geometry(const OgsRasterFwdArgs* a, void* stream_, int64_
     hipStream_t s = static_cast<hipStream_t>(stream_);
     if (num_rendered_host) *num_rendered_host = 0;
     if (a->P == 0) return OGS_OK;
+    rc = check_async_status("forward (entry)");          // sticky: something an EARLIER pass reported after its last check
+    if (rc != OGS_OK) return rc;
     const GeomState gs = GeomState::carve(a->geom_buffer, a->P, a->C);
     const GeomTmp gt = GeomTmp::carve(a->geom_tmp, a->P);
     if (a->P <= kSmallMaxP) {
@@ -221,6 +254,8 @@ int ogs_raster_forward_geometry(const OgsRasterFwdArgs* a, void* stream_, int64_
         OGS_HIP_CHECK(hipMemcpyAsync(&d, gt.num_rendered, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         OGS_HIP_CHECK(hipStreamSynchronize(s));
         *num_rendered_host = (int64_t)d;
+        rc = check_async_status("forward geometry phase");      // the depth sort of THIS pass has finished
+        if (rc != OGS_OK) return rc;
     }
     return OGS_OK;
 }
@@ -338,17 +373,26 @@ int ogs_raster_backward(const OgsRasterBwdArgs* a, void* stream_) {
         set_error("backward: NULL required pointer"); return OGS_ERR_INVALID_ARG;
     }
     if (a->num_rendered > 0 && !a->point_list) { set_error("backward: point_list == NULL"); return OGS_ERR_INVALID_ARG; }
+    // the blend kernels address the gradient record with 32-bit element offsets (g * 16 + slot, SGPR-base atomics)
+    if ((int64_t)a->P * grad_stride(a->C) >= (1ll << 32)) {
+        set_error("backward: P=%d exceeds the %lld Gaussians the 32-bit gradient-record offsets address", a->P,
+                  (long long)((1ll << 32) / grad_stride(a->C)) - 1);
+        return OGS_ERR_UNSUPPORTED;
+    }
+    {
+        const int st = check_async_status("backward (entry)");
+        if (st != OGS_OK) return st;
+    }
     hipStream_t s = static_cast<hipStream_t>(stream_);
     const GeomState gs = GeomState::carve(const_cast<void*>(a->geom_buffer), a->P, a->C);
     if (a->num_groups < 0) { set_error("backward: num_groups=%d", a->num_groups); return OGS_ERR_INVALID_ARG; }
     const ImageState is = ImageState::carve(const_cast<void*>(a->image_buffer), a->W, a->H, num_groups_of(a->num_groups));
     void* grad_rec = a->bwd_tmp;
-    const bool f64 = grad_accum_f64();
-    OGS_HIP_CHECK(hipMemsetAsync(grad_rec, 0, (size_t)a->P * grad_stride(a->C) * (f64 ? sizeof(double) : sizeof(float)), s));
+    OGS_HIP_CHECK(hipMemsetAsync(grad_rec, 0, (size_t)a->P * grad_stride(a->C) * sizeof(double), s));
     if (a->num_rendered > 0 && (!a->sorted_rec || !a->quad_list)) { set_error("backward: sorted_rec / quad_list == NULL"); return OGS_ERR_INVALID_ARG; }
-    int rc = launch_blend_backward(*a, is, grad_rec, f64, s);
+    int rc = launch_blend_backward(*a, is, grad_rec, s);
     if (rc != OGS_OK) return rc;
-    return launch_preprocess_backward(*a, gs, grad_rec, f64, s);
+    return launch_preprocess_backward(*a, gs, grad_rec, s);
 }
 
 int ogs_mark_visible(int32_t P, const float* means3D, const float* viewmatrix, const float*, uint8_t* present,
@@ -385,10 +429,12 @@ int ogs_selftest_tile_order(const uint32_t* ranges, int64_t vtiles, uint32_t* or
 size_t ogs_selftest_radix_tmp_bytes(int64_t n) { return sort_tmp_bytes(n > 0 ? n : 1); }
 
 int ogs_selftest_radix_sort(uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, uint32_t* vals1, int64_t n, int32_t key_bits,
-                            int32_t variant, void* tmp, int32_t* result_buffer, void* stream_) {
+                            int32_t variant, int32_t items, const uint32_t* n_dev, void* tmp, int32_t* result_buffer,
+                            void* stream_) {
     if (!result_buffer) { set_error("selftest_radix_sort: NULL result_buffer"); return OGS_ERR_INVALID_ARG; }
     *result_buffer = 0;
     if (n <= 0) return OGS_OK;
+    if (items != 0 && items != 4 && items != 16) { set_error("selftest_radix_sort: items=%d (0, 4 or 16)", items); return OGS_ERR_INVALID_ARG; }
     if (!keys0 || !vals0 || !keys1 || !vals1 || !tmp || key_bits < 1 || key_bits > 32) {
         set_error("selftest_radix_sort: bad arguments"); return OGS_ERR_INVALID_ARG;
     }
@@ -400,16 +446,24 @@ int ogs_selftest_radix_sort(uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, u
     for (int p = 0; p < passes; ++p) { shifts[p] = p * per; nbits[p] = p == passes - 1 ? key_bits - shifts[p] : per; }
     // variant bit 0: one launch per pass; bit 1: drop mode -- keys equal to 0xFFFFFFFF leave in the first pass (the tile sort of the
     // default binning mode); the number of keys left is returned in bits 1.. of *result_buffer
+    // variant bit 2: the look-back waits of the one-launch passes get a bound of ZERO polls -- fault injection for the
+    // sticky status word: the call must come back with OGS_ERR_DEVICE (and a wrong permutation)
     const bool sweep = (variant & 1) != 0, drop = (variant & 2) != 0;
+    const int spin_limit = (variant & 4) ? 0 : -1;
+    (void)take_async_status();       // the hook reports what THIS sort does
     uint32_t* kept = nullptr;
-    if (drop) OGS_HIP_CHECK(hipMalloc(&kept, sizeof(uint32_t)));
+    if (drop) {
+        OGS_HIP_CHECK(hipMalloc(&kept, sizeof(uint32_t)));
+        // poisoned, as the render phase's scratch is (torch.empty): every path of the first pass must write it
+        OGS_HIP_CHECK(hipMemsetAsync(kept, 0xA5, sizeof(uint32_t), s));
+    }
     int rc = OGS_OK;
-    if (sweep) rc = radix_sort_begin(k[0], n, nullptr, passes, shifts, nbits, tmp, s, 0, drop);
+    if (sweep) rc = radix_sort_begin(k[0], n, n_dev, passes, shifts, nbits, tmp, s, 0, drop, items);
     for (int p = 0; p < passes && rc == OGS_OK; ++p) {
         const int in = p & 1, out = in ^ 1;
         const bool d0 = drop && p == 0;
-        const uint32_t* n_pass = (drop && p > 0) ? kept : nullptr;
-        rc = sweep ? radix_sort_pass(p, passes, k[in], v[in], k[out], v[out], n, shifts[p], nbits[p], tmp, s, 0, n_pass, d0, d0 ? kept : nullptr)
+        const uint32_t* n_pass = (drop && p > 0) ? kept : n_dev;
+        rc = sweep ? radix_sort_pass(p, passes, k[in], v[in], k[out], v[out], n, shifts[p], nbits[p], tmp, s, 0, n_pass, d0, d0 ? kept : nullptr, items, spin_limit)
                    : radix_pass(k[in], v[in], k[out], v[out], n, shifts[p], nbits[p], tmp, s, 0, n_pass, d0, d0 ? kept : nullptr);
     }
     uint32_t kept_host = 0;
@@ -417,10 +471,12 @@ int ogs_selftest_radix_sort(uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, u
         if (rc == OGS_OK && hipMemcpyAsync(&kept_host, kept, sizeof(uint32_t), hipMemcpyDeviceToHost, s) != hipSuccess) rc = OGS_ERR_HIP;
         (void)hipStreamSynchronize(s);
         (void)hipFree(kept);
+    } else {
+        (void)hipStreamSynchronize(s);
     }
     if (rc != OGS_OK) return rc;
     *result_buffer = (passes & 1) | (drop ? (int32_t)(kept_host << 1) : 0);
-    return OGS_OK;
+    return check_async_status("selftest_radix_sort");
 }
 
 int ogs_raster_export_binning(const OgsRasterFwdArgs* a, int64_t D, uint64_t* keys_out, uint32_t* ranges_out,

@@ -37,6 +37,18 @@ void set_error(const char* fmt, ...);
         if (debug) OGS_HIP_CHECK(hipStreamSynchronize(stream));                          \
     } while (0)
 
+// ---- sticky asynchronous device status ------------------------------------------------------------------------------
+// One 32-bit word in pinned, device-mapped host memory (allocated on first use, one per process = one per GPU).  A kernel
+// that detects a condition it cannot recover from ORs a bit into it with a system-scope atomic -- code that never executes
+// in a healthy run, so it costs nothing there -- and carries on without hanging or writing out of bounds.  The host reads
+// (and clears) the word wherever it already synchronises with the stream: after the num_rendered read-back of a forward,
+// at the entry of the next forward / backward, in the self-test hooks; ogs_check_async_status() turns it into
+// OGS_ERR_DEVICE.  Today's only producer: the bounded look-back spin of radix_onesweep_kernel (binning.hip).
+constexpr uint32_t kAsyncRadixSpin = 1u;
+uint32_t* async_status_word();                   // device-usable pointer (nullptr + set_error when the allocation fails)
+int take_async_status();                         // read and clear; 0 = nothing happened (also when never allocated)
+int check_async_status(const char* where);       // OGS_OK, or OGS_ERR_DEVICE with the message set
+
 // ---- optional per-kernel timing (HIP events on the launch stream; used by bench.py) -----------------
 struct ProfScope {
     const char* name;
@@ -129,8 +141,10 @@ struct StreamRec {
 // Per-Gaussian gradient record accumulated by the backward blend: 16 slots (fp64: 128 B = two 64-byte halves, the
 // granularity of the memory-side atomics; one lane group of 16 adds a whole record with one instruction):
 //   [0..8]   dL/dfeature 0..8      [9] dL/ddepth
-//   [10..15] centred pixel moments of q = opacity * G * dL/dalpha: S0, Sx, Sy, Sxx, Sxy, Syy (d = centre - pixel);
-//            preprocess_bwd.hip maps them to dL/dmean2D, dL/dconic, dL/dopacity
+//   [10..15] pixel moments of q = opacity * G * dL/dalpha about the IMAGE ORIGIN: M0, MX, MY, MXX, MXY, MYY = sum over the
+//            Gaussian's pixels (X, Y) of q * {1, X, Y, X^2, XY, Y^2} (round 4; round 2 / 3 shifted them to the Gaussian's
+//            centre inside the blend kernel).  preprocess_bwd.hip re-centres them in fp64 (d = centre - pixel: S0, Sx, Sy,
+//            Sxx, Sxy, Syy) and maps those to dL/dmean2D, dL/dconic, dL/dopacity
 // (blend_bwd.hip: every slot is reduced on the matrix cores).
 // Features-only backward (blend_backward_feat_kernel): channels F0..C-1 sit at slots 0..C-F0-1 (first half only).
 constexpr int kSlotDepth = 9, kSlotMoments = 10;
@@ -219,11 +233,14 @@ int exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out
 // every later pass.  (The tile sort drops the (Gaussian, tile) pairs that cannot reach a pixel of their tile: duplicate_kernel.)
 constexpr uint32_t kDropKey = 0xFFFFFFFFu;
 bool radix_onesweep_enabled(int64_t n);
+// items (0: by size; 4 / 16: the self-test hook forces a tile size) must be the same in radix_sort_begin and every radix_sort_pass
+// of a sort; spin_limit < 0: the default bound of a look-back wait (the self-test hook passes 0 to trip it).
 int radix_sort_begin(const uint32_t* keys, int64_t n, const uint32_t* n_dev, int npass, const int* shifts, const int* bits,
-                     void* tmp, hipStream_t stream, int debug, bool drop = false);
+                     void* tmp, hipStream_t stream, int debug, bool drop = false, int items = 0);
 int radix_sort_pass(int pass, int npass, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out,
                     uint32_t* vals_out, int64_t n, int shift, int bits, void* tmp, hipStream_t stream, int debug,
-                    const uint32_t* n_dev = nullptr, bool drop = false, uint32_t* kept_out = nullptr);
+                    const uint32_t* n_dev = nullptr, bool drop = false, uint32_t* kept_out = nullptr, int items = 0,
+                    int spin_limit = -1);
 // One stable LSD pass on bits [shift, shift+bits) of keys_in (bits <= 8): histogram table, row scan, scatter.
 int radix_pass(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
                int64_t n, int shift, int bits, void* tmp, hipStream_t stream, int debug,
@@ -296,14 +313,13 @@ int launch_tile_ranges(const uint32_t* tile_keys_sorted, int64_t D, uint2* range
 inline int num_groups_of(int g) { return g > 1 ? g : 1; }
 int launch_blend_forward(const OgsRasterFwdArgs& a, const GeomState& gs, const ImageState& is, int64_t D,
                          hipStream_t s);
-// The per-Gaussian gradient record is accumulated either in fp32 (64 B) or in fp64 (128 B = one L2 line; the
-// default): with thousands of float atomics per large Gaussian, arriving in a different order every run and
-// cancelling against each other, an fp32 running sum made the gradients differ run to run by ~1e-4 of their
-// maximum (GPUTEST_r01: rotations at S1M); the fp64 sum is order-insensitive to ~1e-16 and is rounded to fp32
-// ONCE, in preprocess_backward_kernel.
-int launch_blend_backward(const OgsRasterBwdArgs& a, const ImageState& is, void* grad_rec, bool f64, hipStream_t s);
-int launch_preprocess_backward(const OgsRasterBwdArgs& a, const GeomState& gs, const void* grad_rec, bool f64,
-                               hipStream_t s);
+// The per-Gaussian gradient record is accumulated in fp64 (128 B = one L2 line): with thousands of float atomics per
+// large Gaussian, arriving in a different order every run and cancelling against each other, an fp32 running sum made
+// the gradients differ run to run by ~1e-4 of their maximum (GPUTEST_r01: rotations at S1M); the fp64 sum is
+// order-insensitive to ~1e-16 and is rounded to fp32 ONCE, in preprocess_backward_kernel.  (Round 4: the fp32 record of
+// OGS_GRAD_ACCUM=f32 is gone -- the moment slots are sums about the image origin now and NEED the fp64 headroom.)
+int launch_blend_backward(const OgsRasterBwdArgs& a, const ImageState& is, void* grad_rec, hipStream_t s);
+int launch_preprocess_backward(const OgsRasterBwdArgs& a, const GeomState& gs, const void* grad_rec, hipStream_t s);
 // Only dL/dcolors_precomp is requested (every other output pointer NULL): the stage >= 1 training graph
 // (train.py:431-436) -> features-only kernels.
 inline bool backward_is_features_only(const OgsRasterBwdArgs& a) {

@@ -21,14 +21,14 @@ __device__ constexpr float kC3[7] = {-0.5900435899266435f, 2.890611442640554f, -
                                      0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
                                      -0.5900435899266435f};
 
-template <int C, typename ACC>
+template <int C>
 __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
     int P, int W, int H, int sh_degree, int sh_coeffs, float tanfovx, float tanfovy, float focal_x, float focal_y,
     float scale_modifier, const float* __restrict__ means3D, const float* __restrict__ shs,
     const float* __restrict__ scales, const float* __restrict__ rotations, const float* __restrict__ cov3D_precomp,
     const float* __restrict__ viewmatrix, const float* __restrict__ projmatrix, const float* __restrict__ campos,
     const int32_t* __restrict__ radii, const uint32_t* __restrict__ clamped_in, const float4* __restrict__ rec,
-    const ACC* __restrict__ grad_rec,
+    const double* __restrict__ grad_rec,
     float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh,
     float* __restrict__ dL_dscales, float* __restrict__ dL_drotations, float* __restrict__ dL_dsh_rgb,
@@ -51,38 +51,46 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
         s_drgb[tid][0] = 0.f; s_drgb[tid][1] = 0.f; s_drgb[tid][2] = 0.f;
     }
 
-    float gr[16];
-    if constexpr (sizeof(ACC) == 8) {
-        // fp64 running sums, rounded to fp32 once, here
+    // fp64 running sums (ogs_common.h: features 0..8, depth, six moments); the feature / depth slots are rounded to fp32
+    // once, here
+    double g64[16];
+    {
         const double2* g2 = reinterpret_cast<const double2*>(grad_rec + (size_t)idx * GS);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const double2 t = vis ? g2[k] : make_double2(0.0, 0.0);
-            gr[2 * k] = (float)t.x; gr[2 * k + 1] = (float)t.y;
-        }
-    } else {
-        const float4* g4 = reinterpret_cast<const float4*>(grad_rec + (size_t)idx * GS);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float4 t = vis ? g4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
-            gr[4 * k] = t.x; gr[4 * k + 1] = t.y; gr[4 * k + 2] = t.z; gr[4 * k + 3] = t.w;
+            g64[2 * k] = t.x; g64[2 * k + 1] = t.y;
         }
     }
-    // record layout: ogs_common.h (features 0..8, depth, then the six centred moments of q = opacity * G * dL/dalpha
-    // over the Gaussian's pixels: S0, Sx, Sy, Sxx, Sxy, Syy with d = centre - pixel).  The per-(entry, pixel) geometry
-    // partials of the reference's backward blend are this linear map of the moments, applied once per Gaussian:
+    float gr[kSlotMoments];
+#pragma unroll
+    for (int k = 0; k < kSlotMoments; ++k) gr[k] = (float)g64[k];
+    // Slots 10..15: moments of q = opacity * G * dL/dalpha over the Gaussian's pixels (X, Y) about the IMAGE ORIGIN (the blend
+    // kernel's waves only know their quadrant; blend_bwd.hip::PairFold).  Re-centred here on the pixel centre the blend used,
+    // d = centre - pixel, in fp64 -- |X|^2 / sigma^2 can reach ~1e7, far inside the 1e16 of the format:
+    //   S0 = M0   Sx = cx M0 - MX   Sxx = cx^2 M0 - 2 cx MX + MXX   Sxy = cx cy M0 - cx MY - cy MX + MXY   ...
+    // The per-(entry, pixel) geometry partials of the reference's backward blend are this linear map of the centred moments,
+    // applied once per Gaussian:
     //   dL/dmean2D = (W/2, H/2) * sum q * dpower/dd,  dpower/dd = -(A dx + B dy, C dy + B dx)
     //   dL/dconic  = -1/2 sum q * (dx^2, dx dy, dy^2)          dL/dopacity = sum G dL/dalpha = S0 / opacity
     const float d_depth = gr[kSlotDepth];
     float dm2x = 0.f, dm2y = 0.f, dconA = 0.f, dconB = 0.f, dconC = 0.f, dopac = 0.f;
     if (vis && !feat_only_layout) {
+        const float4 ge = rec[(size_t)idx * rec_vec4(C)];              // pixel centre (px, py), depth, radius
         const float4 co = rec[(size_t)idx * rec_vec4(C) + 1];          // conic A, B, C, opacity: what the blend used
-        const float S0 = gr[kSlotMoments], Sx = gr[kSlotMoments + 1], Sy = gr[kSlotMoments + 2];
+        const double cx = (double)ge.x, cy = (double)ge.y;
+        const double M0 = g64[kSlotMoments], MX = g64[kSlotMoments + 1], MY = g64[kSlotMoments + 2];
+        const double MXX = g64[kSlotMoments + 3], MXY = g64[kSlotMoments + 4], MYY = g64[kSlotMoments + 5];
+        const float S0 = (float)M0;
+        const float Sx = (float)(cx * M0 - MX), Sy = (float)(cy * M0 - MY);
+        const float Sxx = (float)(cx * (cx * M0 - 2.0 * MX) + MXX);
+        const float Sxy = (float)(cx * (cy * M0 - MY) - cy * MX + MXY);
+        const float Syy = (float)(cy * (cy * M0 - 2.0 * MY) + MYY);
         dm2x = (-0.5f * (float)W) * (co.x * Sx + co.y * Sy);
         dm2y = (-0.5f * (float)H) * (co.z * Sy + co.y * Sx);
-        dconA = -0.5f * gr[kSlotMoments + 3];
-        dconB = -0.5f * gr[kSlotMoments + 4];
-        dconC = -0.5f * gr[kSlotMoments + 5];
+        dconA = -0.5f * Sxx;
+        dconB = -0.5f * Sxy;
+        dconC = -0.5f * Syy;
         dopac = co.w > 0.f ? S0 / co.w : 0.f;
     }
 
@@ -342,16 +350,16 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
     }
 }
 
-template <int C, typename ACC>
+template <int C>
 int launch_c(const OgsRasterBwdArgs& a, const GeomState& gs, const void* grad_rec, hipStream_t s) {
     const float focal_x = (float)a.W / (2.0f * a.tanfovx);
     const float focal_y = (float)a.H / (2.0f * a.tanfovy);
     const int grid = (a.P + kBlock - 1) / kBlock;
     static constexpr const char* const kNames[4] = {"preprocess_backward_kernel<3>", "preprocess_backward_kernel<6>", "preprocess_backward_kernel<9>", "preprocess_backward_kernel<12>"};
-    OGS_LAUNCH_NAMED(chan_name<C>(kNames), (preprocess_backward_kernel<C, ACC>), dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, a.sh_degree,
+    OGS_LAUNCH_NAMED(chan_name<C>(kNames), (preprocess_backward_kernel<C>), dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, a.sh_degree,
                        a.sh_coeffs, a.tanfovx, a.tanfovy, focal_x, focal_y, a.scale_modifier, a.means3D, a.shs, a.scales,
                        a.rotations, a.cov3D_precomp, a.viewmatrix, a.projmatrix, a.campos, a.radii,
-                       (const uint32_t*)gs.clamped, (const float4*)gs.rec, (const ACC*)grad_rec, a.dL_dmeans2D, a.dL_dcolors, a.dL_dopacity, a.dL_dmeans3D,
+                       (const uint32_t*)gs.clamped, (const float4*)gs.rec, (const double*)grad_rec, a.dL_dmeans2D, a.dL_dcolors, a.dL_dopacity, a.dL_dmeans3D,
                        a.dL_dcov3D, a.dL_dsh, a.dL_dscales, a.dL_drotations, a.dL_dsh_rgb,
                        backward_is_features_only(a) ? 1 : 0);
     OGS_LAUNCH_CHECK(a.debug, s);
@@ -430,12 +438,12 @@ int launch_sh_grad_from_views(int P, int V, int sh_degree, int sh_coeffs, const 
     return OGS_OK;
 }
 
-int launch_preprocess_backward(const OgsRasterBwdArgs& a, const GeomState& gs, const void* grad_rec, bool f64, hipStream_t s) {
+int launch_preprocess_backward(const OgsRasterBwdArgs& a, const GeomState& gs, const void* grad_rec, hipStream_t s) {
     if (a.P <= 0) return OGS_OK;
     switch (a.C) {
-        case 3: return f64 ? launch_c<3, double>(a, gs, grad_rec, s) : launch_c<3, float>(a, gs, grad_rec, s);
-        case 6: return f64 ? launch_c<6, double>(a, gs, grad_rec, s) : launch_c<6, float>(a, gs, grad_rec, s);
-        case 9: return f64 ? launch_c<9, double>(a, gs, grad_rec, s) : launch_c<9, float>(a, gs, grad_rec, s);
+        case 3: return launch_c<3>(a, gs, grad_rec, s);
+        case 6: return launch_c<6>(a, gs, grad_rec, s);
+        case 9: return launch_c<9>(a, gs, grad_rec, s);
         default: set_error("backward: unsupported channel count C=%d", a.C); return OGS_ERR_UNSUPPORTED;
     }
 }

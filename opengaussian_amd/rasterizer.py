@@ -243,6 +243,9 @@ def _streaming_render(a: OgsRasterFwdArgs, dev, lib, debug: bool):
         point_list, bin_tmp, sorted_rec, quad_list = alloc_render(cap)
         check(lib.ogs_raster_forward_render_deferred(C.byref(a), cap, stream), "ogs_raster_forward_render_deferred")
         ev.synchronize()
+        # the geometry phase of THIS pass (its depth sort) and every earlier launch have finished: anything a kernel reported
+        # through the sticky status word (a one-launch radix pass whose bounded look-back wait ran out) raises here
+        check(lib.ogs_check_async_status(), "ogs_check_async_status")
         D = int(pinned.item()) & 0xFFFFFFFF
         if D > cap:
             PASS_STATS["overflow"] += 1

@@ -45,7 +45,6 @@ READ_PATTERN = {
     "tile_order_kernel": ("small table", False),
     "blend_forward_kernel": ("SCALAR loads of the record stream (s_load_dwordx16) + one-dword-per-line vector prefetch touches", False),
     "blend_forward_rows_kernel": ("per-lane 16-byte gathers of 80-byte records (L2 resident after the line-touch prefetch) + the prefetch touches", False),
-    "blend_backward_rows_kernel": ("per-lane 16-byte gathers of records + per-pixel 4-byte loads; writes are fp64 atomics", False),
     "blend_backward_kernel": ("SCALAR loads of the record stream + line touches + per-pixel 4-byte loads; writes are fp64 atomics", False),
     "blend_backward_feat_kernel": ("SCALAR loads of the record stream + line touches; writes are fp64 atomics", False),
     "blend_backward_feat_lds_kernel": ("per-lane 16-byte gathers of the records' geometry halves + line touches; writes are fp64 atomics", False),

@@ -1,15 +1,14 @@
 #!/bin/bash
 # A-B of the radix sort variants on ONE box (OGS_RADIX=legacy: three launches per pass; default: one launch per pass with
-# decoupled look-back; OGS_SWEEP_ITEMS forces the tile size).  Prints ms/step and the radix kernels' ms per step.
+# decoupled look-back).  Prints ms/step and the radix kernels' ms per step.  (The tile-size switch OGS_SWEEP_ITEMS of
+# round 3 is gone: forced tile sizes are an argument of the radix self-test hook, tests/test_13_radix_gpu.py.)
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 for wl in C2-100k-800 S1M-1080p; do
-  for mode in legacy sweep sweep4 sweep16; do
+  for mode in legacy sweep; do
     case $mode in
-      legacy) export OGS_RADIX=legacy; unset OGS_SWEEP_ITEMS;;
-      sweep) unset OGS_RADIX; unset OGS_SWEEP_ITEMS;;
-      sweep4) unset OGS_RADIX; export OGS_SWEEP_ITEMS=4;;
-      sweep16) unset OGS_RADIX; export OGS_SWEEP_ITEMS=16;;
+      legacy) export OGS_RADIX=legacy;;
+      sweep) unset OGS_RADIX;;
     esac
     timeout -k 10 200 python bench.py --workload $wl --steps 100 --warmup 10 --no-cpu-baseline --no-kmeans > gpurun_out/ab_${wl}_${mode}.json 2> gpurun_out/ab_${wl}_${mode}.err || exit 1
     python - "$wl" "$mode" <<'PY'

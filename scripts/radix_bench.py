@@ -30,7 +30,7 @@ for key_bits in (32, 13):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 _lib.check(lib.ogs_selftest_radix_sort(k[0].data_ptr(), v[0].data_ptr(), k[1].data_ptr(), v[1].data_ptr(), n, key_bits,
-                                                       variant, tmp.data_ptr(), C.byref(res), stream), "radix")
+                                                       variant, 0, None, tmp.data_ptr(), C.byref(res), stream), "radix")
                 e1.record(); e1.synchronize()
                 if rep >= 3:
                     ts.append(e0.elapsed_time(e1) * 1e3)

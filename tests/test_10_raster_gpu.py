@@ -355,6 +355,57 @@ def test_deferred_render_phase_and_capacity_overflow(gpu_device):
         cc.backward(g)
 
 
+def test_view_that_sees_nothing_rendered_twice_runs_the_deferred_phase_on_a_zero_count(gpu_device):
+    """ADVICE r3 (high).  A pass whose camera sees nothing records num_rendered = 0, so the NEXT pass at that size is deferred with
+    the minimum capacity (4096) and a device-side count of 0.  In drop mode tile 0 of the one-launch tile sort used to return
+    before storing the kept count; the later passes, tile_ranges_kernel and pack then read an uninitialised word (torch.empty) as
+    their element count -> ranges[] written at garbage tile ids / a stale list blended.  P above the tiny and small limits, G = 1;
+    the allocator's free blocks are poisoned before every pass.  Expect: background only, every range empty, both ways of sizing
+    the render phase, and a later pass that DOES see the scene at the same size (capacity overflow) unharmed."""
+    from opengaussian_amd import rasterizer as R
+    W, H, f = 160, 96, 120.0
+    P = 3000
+    sc, cam = helpers.tiny_scene(P, W, H, f, seed=77)
+    inp = helpers.oracle_inputs(sc, cam, use_sh=True)
+    hidden = dict(inp)
+    m = inp["means3D"].copy(); m[:, 2] = -np.abs(m[:, 2]) - 1.0              # everything behind the camera
+    hidden["means3D"] = m
+    bg = (0.5, 0.25, 0.125)
+    key = (P, W, H, 1)
+    R._LAST_NUM_RENDERED.pop(key, None)
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+
+    def poison():
+        junk = [torch.full((n,), -1, dtype=torch.int32, device=gpu_device) for n in (1 << 10, 1 << 14, 1 << 18, 1 << 22)]
+        del junk
+
+    stats0 = dict(R.PASS_STATS)
+    for sized in ("blocking", "deferred", "deferred"):
+        poison()
+        (c, r, d, a), _ = helpers.hip_forward(hidden, cam, bg, 3, gpu_device, requires_grad=True)
+        assert c.grad_fn.num_rendered == 0 and int(r.abs().sum()) == 0
+        want = torch.tensor(bg, device=gpu_device).view(3, 1, 1).expand(3, H, W)
+        assert torch.equal(c, want), sized
+        assert float(a.abs().max()) == 0.0 and float(d.abs().max()) == 0.0
+        image = c.grad_fn.saved_tensors[14]                                  # ImageState: ranges[tiles] come first
+        ranges = image[: tiles * 8].view(torch.int32)
+        assert int(ranges.abs().sum()) == 0, sized
+        c.sum().backward()                                                   # nothing to do, must not fault
+    assert R.PASS_STATS["deferred"] - stats0["deferred"] == 2 and R.PASS_STATS["blocking"] - stats0["blocking"] == 1
+    # the same size, now visible: the capacity hint (4096) overflows, the render phase is redone with exact buffers
+    poison()
+    (c1, r1, d1, a1), _ = helpers.hip_forward(inp, cam, bg, 3, gpu_device)
+    R._LAST_NUM_RENDERED.pop(key, None)
+    (c2, r2, d2, a2), _ = helpers.hip_forward(inp, cam, bg, 3, gpu_device)   # fresh blocking pass
+    assert torch.equal(c1, c2) and torch.equal(r1, r2) and torch.equal(a1, a2)
+    assert _lib_status_clear()
+
+
+def _lib_status_clear():
+    from opengaussian_amd import _lib
+    return _lib.lib().ogs_check_async_status() == 0
+
+
 def test_noncontiguous_inputs(gpu_device):
     """render() feeds sliced / boolean-indexed views (gaussian_renderer/__init__.py:133,204-212)."""
     from opengaussian_amd.rasterizer import GaussianRasterizer
@@ -758,11 +809,12 @@ def test_random_configurations_forward_parity(gpu_device):
             raise AssertionError(f"{tag}: {e}") from None
 
 
-@pytest.mark.parametrize("env", [{"OGS_BLEND_ROWS": "0"}, {"OGS_BLEND_ROWS_BWD": "1"}, {"OGS_BLEND_FEAT_LDS": "0"},
+@pytest.mark.parametrize("env", [{"OGS_BLEND_ROWS": "0"}, {"OGS_BLEND_FOLD": "f32"}, {"OGS_BLEND_FEAT_LDS": "0"},
                                  {"OGS_PACK_FUSED": "0"}])
 def test_alternative_blend_kernels_keep_parity(gpu_device, env):
-    """The blend kernels exist in two structures each: the quadrant walk (records in SGPRs) and the per-4x4-block walk
-    (records in VGPRs through LDS).  Defaults: forward = per-block, backward = quadrant (measured); the
+    """The forward blend exists in two structures: the quadrant walk (records in SGPRs) and the per-4x4-block walk (records in
+    VGPRs through LDS, the default).  The full backward reduces its gradient records on the matrix cores with a two-term bf16
+    split of both operands by default and with exact-fp32 MFMAs under OGS_BLEND_FOLD=f32 (the round-2 / 3 product); the
     features-only backward walks quadrants with its records through LDS by default, through scalar loads otherwise; pack and
     forward blend of a tile run in one workgroup by default, as two launches otherwise.  The
     non-default ones are selected by environment variables read once per process, so they are checked in a child process:

@@ -11,7 +11,7 @@ from opengaussian_amd import _lib
 pytestmark = pytest.mark.gpu
 
 
-def _sort(keys, key_bits, variant, dev):
+def _sort(keys, key_bits, variant, dev, items=0):
     lib = _lib.lib()
     n = keys.numel()
     tmp = torch.empty(int(lib.ogs_selftest_radix_tmp_bytes(n)), dtype=torch.uint8, device=dev)
@@ -19,7 +19,8 @@ def _sort(keys, key_bits, variant, dev):
     v = [torch.arange(n, dtype=torch.int32, device=dev), torch.full((n,), -1, dtype=torch.int32, device=dev)]
     res = C.c_int32(-1)
     _lib.check(lib.ogs_selftest_radix_sort(k[0].data_ptr(), v[0].data_ptr(), k[1].data_ptr(), v[1].data_ptr(), n, key_bits, variant,
-                                           tmp.data_ptr(), C.byref(res), torch.cuda.current_stream().cuda_stream), "radix")
+                                           items, None, tmp.data_ptr(), C.byref(res), torch.cuda.current_stream().cuda_stream),
+               "radix")
     torch.cuda.synchronize()
     return k[res.value], v[res.value]
 
@@ -62,7 +63,7 @@ def test_radix_sort_adversarial_keys(gpu_device):
     _check(alt.contiguous(), 32, dev, "two extreme values alternating")
 
 
-def _sort_drop(keys, key_bits, variant, dev):
+def _sort_drop(keys, key_bits, variant, dev, n_dev=None):
     lib = _lib.lib()
     n = keys.numel()
     tmp = torch.empty(int(lib.ogs_selftest_radix_tmp_bytes(n)), dtype=torch.uint8, device=dev)
@@ -70,7 +71,8 @@ def _sort_drop(keys, key_bits, variant, dev):
     v = [torch.arange(n, dtype=torch.int32, device=dev), torch.full((n,), -1, dtype=torch.int32, device=dev)]
     res = C.c_int32(-1)
     _lib.check(lib.ogs_selftest_radix_sort(k[0].data_ptr(), v[0].data_ptr(), k[1].data_ptr(), v[1].data_ptr(), n, key_bits, variant | 2,
-                                           tmp.data_ptr(), C.byref(res), torch.cuda.current_stream().cuda_stream), "radix")
+                                           0, None if n_dev is None else n_dev.data_ptr(), tmp.data_ptr(), C.byref(res),
+                                           torch.cuda.current_stream().cuda_stream), "radix")
     torch.cuda.synchronize()
     kept = res.value >> 1
     return k[res.value & 1][:kept], v[res.value & 1][:kept], kept
@@ -94,3 +96,52 @@ def test_radix_sort_drop_mode_is_the_stable_sort_of_the_kept_keys(gpu_device, n,
         assert kept == keep_idx.numel(), (variant, kept, keep_idx.numel())
         assert torch.equal(k.to(torch.int64).cpu() & 0xFFFFFFFF, want_k), f"keys, variant {variant}"
         assert torch.equal(v.to(torch.int64).cpu(), want_v), f"stable order, variant {variant}"
+
+
+@pytest.mark.parametrize("items", [4, 16])
+def test_one_launch_sort_with_a_forced_tile_size_at_4m_keys(gpu_device, items):
+    """The configuration of the round-3 memory fault (gpurun_out/ab_S1M-1080p_sweep4.err: one-launch passes with 1024-key tiles
+    over the 7.4 M (Gaussian, tile) pairs of the headline scene; DESIGN.md section 3 "the round-3 fault"): 4 Mi + 3 keys through
+    radix_onesweep_kernel<4> need 4 x 4097 x 256 status words, which ogs_selftest_radix_tmp_bytes / sort_tmp_bytes must cover.
+    The tile size is an explicit argument of the hook now (no environment switch); 16 for the other instantiation."""
+    n = (4 << 20) + 3
+    g = torch.Generator().manual_seed(items)
+    keys = torch.randint(0, 1 << 13, (n,), generator=g, dtype=torch.int32).to(gpu_device)        # 13-bit tile ids, two passes
+    k, v = _sort(keys, 13, 1, gpu_device, items=items)
+    want_k, want_v = torch.sort(keys.to(torch.int64), stable=True)
+    assert torch.equal(k.to(torch.int64), want_k)
+    assert torch.equal(v.to(torch.int64), want_v)
+    lib = _lib.lib()
+    tiles4 = (n + 1023) // 1024
+    assert int(lib.ogs_selftest_radix_tmp_bytes(n)) >= 4 * 256 * 4 * tiles4, "scratch must hold four 1024-key-tile status tables"
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_drop_mode_with_a_device_count_of_zero_reports_zero_kept(gpu_device, variant):
+    """a deferred-capacity render phase whose view sees nothing runs the tile sort with *n_dev == 0.  Tile 0 of
+    the one-launch pass used to return before storing the kept count, which the later passes, the tile ranges and pack read from
+    (uninitialised) device memory.  The hook poisons the word first: both implementations must report 0."""
+    n = 5000
+    keys = torch.randint(0, 1 << 13, (n,), dtype=torch.int32).to(gpu_device)
+    n_dev = torch.zeros(1, dtype=torch.int32, device=gpu_device)
+    _, _, kept = _sort_drop(keys, 13, variant, gpu_device, n_dev=n_dev)
+    assert kept == 0
+    n_dev.fill_(1234)                                   # and a true count below the capacity
+    k, v, kept = _sort_drop(keys, 13, variant, gpu_device, n_dev=n_dev)
+    want_k, order = torch.sort(keys[:1234].to(torch.int64), stable=True)
+    assert kept == 1234
+    assert torch.equal(k.to(torch.int64), want_k) and torch.equal(v.to(torch.int64), order)
+
+
+def test_look_back_bound_of_zero_polls_raises(gpu_device):
+    """a one-launch pass whose look-back wait runs out used to set a device word nobody read -- wrong order,
+    rc 0.  Fault injection through the hook (variant bit 2: bound = 0 polls; with 1000 tiles some workgroup always finds a
+    predecessor unpublished): the call must fail with OGS_ERR_DEVICE, the sticky word must be clear afterwards, and the next sort
+    must be correct again."""
+    lib = _lib.lib()
+    n = 1_000_003
+    keys = torch.randint(0, 2 ** 31 - 1, (n,), dtype=torch.int32).to(gpu_device)
+    with pytest.raises(_lib.OgsError, match="look-back"):
+        _sort(keys, 32, 1 | 4, gpu_device, items=4)
+    assert lib.ogs_check_async_status() == 0
+    _check(keys, 32, gpu_device, "after the injected fault")
