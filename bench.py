@@ -76,6 +76,11 @@ def parse():
                          "region); 'sync' = each step waits for its own exchange before the next render starts")
     ap.add_argument("--dense-sh-allreduce", action="store_true",
                     help="N > 1: all-reduce the dense [P,16,3] SH gradient instead of all-gathering its rank-1 factor")
+    ap.add_argument("--stage1", action="store_true",
+                    help="time the STAGE-1 training step instead of the all-gradient step: everything but ins_feat detached "
+                         "(train.py:431-436) -> fused 9-channel forward + features-only backward; for N > 1 the only exchange "
+                         "is the SUM all-reduce of dL/d ins_feat (24 B per Gaussian).  Without this flag an N > 1 run still "
+                         "reports that step as the untimed extra `dist.stage1` (both curves from the driver's one command)")
     ap.add_argument("--separate-passes", action="store_true",
                     help="render RGB and the 6-ch ins_feat map as two rasterizer passes (reference structure) "
                          "instead of the single fused 9-channel pass")
@@ -98,7 +103,7 @@ def algorithmic_bytes(P, D, npx, C, K_in, S=6):
     b["blend_forward_kernel"] = D * (28 + 4 * C + 4) + npx * (4 * C + 12)
     # the fused pack + blend kernel does what the reference's forward blend does per list entry (gather the Gaussian's
     # data, blend it): same algorithmic bytes; the stand-alone per-block blend kernel likewise
-    b["pack_blend_forward_kernel"] = b["blend_forward_rows_kernel"] = b["blend_forward_kernel"]
+    b["pack_blend_chunked_kernel"] = b["pack_blend_forward_kernel"] = b["blend_forward_rows_kernel"] = b["blend_forward_kernel"]
     b["blend_backward_kernel"] = npx * (4 * C + 16) + D * (28 + 4 * C + 4) + D * 2 * (4 * C + 28)
     b["preprocess_backward_kernel"] = P * (44 + 4 * K_in + 4 + 4 * C + 28) + P * (40 + 4 * K_in)
     b["fwd"] = b["preprocess_kernel"] + b["binning"] + b["blend_forward_kernel"]
@@ -211,6 +216,51 @@ def kmeans_bench(device):
                                            "frac": flops / (acc * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS},
                            "limiter": "vector issue of the operand packing / argmax around the MFMAs (DESIGN.md section 4)"}
     return out
+
+
+def kmeans_leaf_bench(device):
+    """Fine level of the two-level codebook (BASELINE config 4: "coarse+fine k-means"): after one coarse assignment of the
+    N = 2 M / k1 = 64 workload, ALL 64 leaf assignments -- Quantize_kMeans.cluster_assign(mode="leaf", selected_leaf=c) for
+    c = 0..63, k2 = 5 (scripts/train_scannet.sh:42-43), d = 6, 5 Lloyd iterations each on the ~31 k points of coarse cluster
+    c (scene/kmeans_quantize.py:195-206,232-240; train.py:321-330 calls one of them every 50 iterations of stage 2.2).
+    Reported: Lloyd it/s over the 64 calls, ms per leaf assign, and the share of that time spent in equalize_cluster_size
+    (the per-call index-table rebuild, scene/kmeans_quantize.py:89-144), measured by running the same calls without it."""
+    from opengaussian_amd.kmeans import Quantize_kMeans
+    g = torch.Generator().manual_seed(0)
+    N, k1, k2, iters = 2_000_000, 64, 5, 5
+    feat6 = torch.rand(N, 6, generator=g).to(device)
+    xyz = torch.randn(N, 3, generator=g).to(device)
+    q = Quantize_kMeans(num_clusters=k1, num_leaf_clusters=k2, num_iters=iters, dim=9, dim_leaf=6)
+    q.cluster_assign(torch.cat([feat6, xyz], dim=1), mode="root")
+    q.iLeafSubNum = torch.full((k1,), k2, dtype=torch.int64, device=device)
+
+    def sweep():
+        for c in range(k1):
+            q.cluster_assign(feat6, mode="leaf", selected_leaf=c)
+    sweep()                                   # warm-up: leaf centres initialised, allocator warm
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sweep()
+    torch.cuda.synchronize()
+    t_full = time.perf_counter() - t0
+    keep = q.equalize_cluster_size
+    q.equalize_cluster_size = lambda mode="root": None
+    try:
+        sweep()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sweep()
+        torch.cuda.synchronize()
+        t_core = time.perf_counter() - t0
+    finally:
+        q.equalize_cluster_size = keep
+    pts = [int((q.cls_ids == c).sum()) for c in (0, k1 // 2, k1 - 1)]
+    return {"leaf_assigns": k1, "k2": k2, "d": 6, "iters_per_assign": iters, "points_per_coarse_cluster_sample": pts,
+            "ms_per_leaf_assign": t_full / k1 * 1e3, "it_per_s": k1 * iters / t_full,
+            "ms_per_leaf_assign_without_equalize": t_core / k1 * 1e3,
+            "equalize_cluster_size_share": max(0.0, 1.0 - t_core / t_full),
+            "note": "host-paced: a leaf assign is ~10 launches on ~31 k rows plus the boolean-index gather / scatter of the "
+                    "coarse cluster's points (as the reference does)"}
 
 
 def kmeans_cpu_baseline():
@@ -490,10 +540,54 @@ def main():
                 bucket_b.wait()
         return radii
 
+    # ---- the stage-1 training step (train.py:431-436: every parameter but ins_feat detached): fused 9-channel forward,
+    # features-only backward; data-parallel exchange = ONE SUM all-reduce of dL/d ins_feat [P, 6], double-buffered like the
+    # all-gradient step (the exchange of view i overlaps the render of view i + 1 and is completed right after it is enqueued)
+    s1 = {"i": 0, "feat": None, "buckets": [], "mode": "pipelined"}
+
+    def stage1_setup():
+        if s1["feat"] is None:
+            s1["feat"] = leaves["ins_feat"].detach().clone().requires_grad_(True)
+            s1["det"] = {k: v.detach() for k, v in leaves.items()}
+            s1["gC9"] = torch.cat([torch.zeros(3, H, W, device=device), gF])
+            if dist_on:
+                s1["buckets"] = [dp.GradBucket([leaves["ins_feat"].shape], device, average=False) for _ in range(2)]
+
+    def step_stage1():
+        stage1_setup()
+        i = s1["i"]
+        s1["i"] = i + 1
+        det, feat = s1["det"], s1["feat"]
+        m2 = torch.zeros(P, 3, device=device)                 # no grad: nothing consumes dL/dmeans2D after stage 0
+        color, radii, depth, alpha = rasterize_fused(det["means3D"], m2, det["opacities"], det["shs"], feat,
+                                                     all_settings[view_of(i, rank)], scales=det["scales"],
+                                                     rotations=det["rotations"])
+        info["D"] = color.grad_fn.num_rendered
+        info["D_seen"].append(info["D"])
+        feat.grad = None
+        color.backward(s1["gC9"])
+        if s1["buckets"] and s1["mode"] != "none":
+            b = s1["buckets"][i % 2] if s1["mode"] == "pipelined" else s1["buckets"][0]
+            b.pack([feat.grad])
+            b.allreduce_async()
+            (s1["buckets"][(i - 1) % 2] if s1["mode"] == "pipelined" else b).wait()
+        return radii
+
+    def drain_stage1():
+        for b in s1["buckets"]:
+            b.wait()
+
     def barrier():
         if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.stage1:
+        if not fused:
+            raise SystemExit("--stage1 times the fused 9-channel step (drop --separate-passes / --rgb-only)")
+        s1["mode"] = args.exchange
+        step_all, drain_all = step, drain              # keep the all-gradient step for the extras
+        step, drain = step_stage1, drain_stage1
 
     # the warm-up steps bracket both blend kernels (mode 2, prefix "blend_") to learn which one dominates the step
     _lib.prof_filter("blend_")
@@ -554,6 +648,7 @@ def main():
         nb = max(2, min(args.steps, 20))
         for mode in [m for m in ("pipelined", "sync", "none") if m != args.exchange]:
             info["xmode"] = mode
+            s1["mode"] = mode
             for _ in range(2):
                 step()
             drain()
@@ -569,7 +664,75 @@ def main():
                 dist.all_reduce(tm, op=dist.ReduceOp.MAX)
             xtimes[mode] = float(tm.item())
         info["xmode"] = args.exchange
+        s1["mode"] = args.exchange
         log(f"exchange modes (ms/step): {xtimes}")
+
+    def max_over_ranks(x):
+        t = torch.tensor([x], device=device, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # N > 1, untimed extras: (a) every collective of the exchange ALONE -- issued on its side stream
+    # exactly as the steps issue it, nothing else on the GPU, barrier + max over ranks -- so that whoever reads an 8-GPU
+    # line can tell link time from compute time; (b) the other training step (stage 1 when the all-gradient step was
+    # timed, and vice versa) through the same pipelined exchange: both scaling curves out of the driver's one command.
+    coll, other_step = None, None
+    if dist_on and fused and not args.no_extras:
+        def time_collective(fn, reps=6):
+            fn()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return max_over_ranks((time.perf_counter() - t1) / reps * 1e3)
+        coll = {}
+        ar_bus = 2.0 * (world - 1) / max(world, 1)              # ring all-reduce: bytes on each link per payload byte
+        if sets:
+            st = sets[0]
+            finish(st)
+            nbytes = st["bucket"].flat.numel() * 4
+            st["bucket"].flat.zero_()
+            ms = time_collective(lambda: (st["bucket"].allreduce_async(), st["bucket"].wait()))
+            coll["grad_bucket_sum_allreduce"] = {"bytes": nbytes, "ms": ms, "busbw_GBps": nbytes * ar_bus / (ms * 1e-3) / 1e9}
+            if st["sh"] is not None:
+                fac = torch.zeros(P, 3, device=device)
+                ms = time_collective(lambda: (st["sh"].gather_async(fac), st["sh"].wait()))
+                coll["sh_factor_allgather"] = {"bytes_per_rank": P * 12, "ms": ms,
+                                               "busbw_GBps": P * 12 * (world - 1) / (ms * 1e-3) / 1e9}
+                ms = time_collective(lambda: st["sh"].rebuild(leaves["means3D"], campos_views[[view_of(0, r) for r in range(world)]],
+                                                              3, out=st["dsh"]))
+                coll["sh_rebuild_kernel"] = {"ms": ms}
+        rad = torch.zeros(P, dtype=torch.int32, device=device)
+        ms = time_collective(lambda: dp.reduce_max_radii(rad)[0])
+        coll["radii_max_allreduce"] = {"bytes": P * 4, "ms": ms, "busbw_GBps": P * 4 * ar_bus / (ms * 1e-3) / 1e9}
+        stage1_setup()
+        if s1["buckets"]:
+            b1 = s1["buckets"][0]
+            b1.flat.zero_()
+            ms = time_collective(lambda: (b1.allreduce_async(), b1.wait()))
+            coll["stage1_ins_feat_sum_allreduce"] = {"bytes": P * 24, "ms": ms, "busbw_GBps": P * 24 * ar_bus / (ms * 1e-3) / 1e9}
+        log(f"collectives alone (ms): { {k: round(v['ms'], 4) for k, v in coll.items()} }")
+        # (b) the other step
+        o_step, o_drain, o_name = ((step_all, drain_all, "all-gradient step (stage 0)") if args.stage1
+                                   else (step_stage1, drain_stage1, "stage-1 step (features-only backward, ins_feat all-reduce)"))
+        nb = max(4, min(args.steps, 40))
+        for _ in range(3):
+            o_step()
+        o_drain()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(nb):
+            o_step()
+        o_drain()
+        torch.cuda.synchronize()
+        barrier()
+        o_ms = max_over_ranks((time.perf_counter() - t1) / nb * 1e3)
+        other_step = {"step": o_name, "ms_per_step": o_ms, "Mpix_per_s_all_ranks": world * W * H / (o_ms * 1e-3) / 1e6,
+                      "exchange": "pipelined", "steps": nb,
+                      "exchange_bytes_per_step_per_rank": (P * 24 if not args.stage1 else None)}
+        log(f"other step: {other_step}")
     # who took part: every rank reports its device, gathered to rank 0 (lets a reader verify that N ranks on N
     # devices really ran under the backend named)
     dist_info = None
@@ -581,7 +744,9 @@ def main():
         everyone = [None] * world
         dist.all_gather_object(everyone, mine)
         xbytes = 0
-        if sets:
+        if args.stage1:
+            xbytes = P * 24
+        elif sets:
             xbytes = sets[0]["bucket"].flat.numel() * 4 + P * 4
             if sets[0]["sh"] is not None:
                 xbytes += world * P * 3 * 4
@@ -589,10 +754,13 @@ def main():
                      "devices_visible_per_rank": torch.cuda.device_count(),
                      "exchange_mode_timed": args.exchange,
                      "exchange_bytes_per_step_per_rank": xbytes,
-                     "exchange_messages": ("flat SUM all-reduce %d B + all-gather of the [P,3] SH-gradient factor %d B "
-                                           "per rank + int32 MAX all-reduce %d B" %
-                                           (sets[0]["bucket"].flat.numel() * 4,
-                                            P * 12 if sets[0]["sh"] is not None else 0, P * 4)) if sets else None,
+                     "exchange_messages": (("SUM all-reduce of dL/d ins_feat, %d B" % (P * 24)) if args.stage1 else
+                                           ("flat SUM all-reduce %d B + all-gather of the [P,3] SH-gradient factor %d B "
+                                            "per rank + int32 MAX all-reduce %d B" %
+                                            (sets[0]["bucket"].flat.numel() * 4,
+                                             P * 12 if sets[0]["sh"] is not None else 0, P * 4)) if sets else None),
+                     "collectives_alone": coll,
+                     ("stage0_all_gradient_step" if args.stage1 else "stage1"): other_step,
                      "ms_per_step_by_exchange_mode": {args.exchange: elapsed / args.steps * 1e3, **xtimes},
                      "exposed_exchange_ms_per_step": (elapsed / args.steps * 1e3 - xtimes["none"]) if "none" in xtimes else None,
                      "sync_minus_pipelined_ms_per_step": ((xtimes.get("sync", elapsed / args.steps * 1e3) -
@@ -678,7 +846,9 @@ def main():
             "value": value, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload + (" RGB(SH3) fwd+bwd only" if args.rgb_only else
+            "config": {"workload": args.workload + (" STAGE-1 step: RGB(SH3)+6-ch ins_feat fused 9-channel forward, features-only backward "
+                                                    "(everything but ins_feat detached, train.py:431-436)" if args.stage1 else
+                                                    " RGB(SH3) fwd+bwd only" if args.rgb_only else
                                                     (" RGB(SH3)+depth+alpha (all grads) + 6-ch ins_feat (grad to ins_feat) fwd+bwd, " +
                                                      ("ONE fused 9-channel pass" if fused else "two passes (3ch SH + 6ch)"))),
                        "gaussians": P, "width": W, "height": H, "views_per_step": world, "views_cycled": V,
@@ -707,6 +877,10 @@ def main():
             try:
                 log("k-means bench")
                 out["kmeans"] = kmeans_bench(device)
+                try:
+                    out["kmeans"]["leaf"] = kmeans_leaf_bench(device)
+                except Exception as e:
+                    out["kmeans"]["leaf"] = {"error": repr(e)}
             except Exception as e:   # k-means is the second half of the metric, never the headline value
                 out["kmeans"] = {"error": repr(e)}
         if world == 1 and not args.no_extras:

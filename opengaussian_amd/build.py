@@ -47,12 +47,12 @@ def _newest_header() -> float:
     return max(os.path.getmtime(h) for h in hs)
 
 
-def _compile(src: str, force: bool) -> str:
-    obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+def _compile(src: str, force: bool, objdir: str = OBJDIR, defines=()) -> str:
+    obj = os.path.join(objdir, src.replace(".hip", ".o"))
     spath = os.path.join(CSRC, src)
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(spath), _newest_header()):
         return obj
-    cmd = [hipcc(), *COMMON, *EXTRA.get(src, []), "-c", spath, "-o", obj]
+    cmd = [hipcc(), *COMMON, *EXTRA.get(src, []), *defines, "-c", spath, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
@@ -77,5 +77,33 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+def build_variant(name: str, defines, verbose: bool = True, only=()) -> str:
+    """A-B timing of kernel variants on ONE box: the same sources compiled with extra -D switches into
+    lib/variants/libogs_hip_<name>.so (git-ignored like every .so, travels with the gpurun snapshot); a bench run picks it
+    up through OGS_LIB_PATH.  Never loaded by the product unless that variable names it."""
+    vdir = os.path.join(LIBDIR, "variants")
+    odir = os.path.join(OBJDIR, "variant_" + name)
+    os.makedirs(vdir, exist_ok=True)
+    os.makedirs(odir, exist_ok=True)
+    srcs = sources()
+    build(verbose=False)        # the default objects: sources not named in `only` are linked from there
+    with ThreadPoolExecutor(max_workers=min(4, len(srcs))) as ex:
+        objs = list(ex.map(lambda s: _compile(s, True, odir, tuple(defines)) if (not only or s in only)
+                           else os.path.join(OBJDIR, s.replace(".hip", ".o")), srcs))
+    lib = os.path.join(vdir, f"libogs_hip_{name}.so")
+    cmd = [hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-o", lib, *objs]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        print(f"[opengaussian_amd.build] variant {name}: {lib} ({' '.join(defines)})")
+    return lib
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        build_variant(sys.argv[i + 1], [a for a in sys.argv[i + 2:] if a.startswith("-D")],
+                      only=tuple(a for a in sys.argv[i + 2:] if a.endswith(".hip")))
+    else:
+        build(force="--force" in sys.argv)

@@ -33,6 +33,7 @@ namespace {
 
 constexpr float kAlphaMin = 1.0f / 255.0f;
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));   // register pair -> v_pk_add_f32 / v_pk_mul_f32
 // Timing ablation "run without the gradient atomics" (OGS_BLEND_PREFETCH bits 8 / 9): results are WRONG by construction, so the
 // predicate only exists in a -DOGS_EXPERIMENTS build; the shipped library compiles it to `false`
 #ifdef OGS_EXPERIMENTS
@@ -410,12 +411,16 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     // rotation), unconditional prefetch (the stream is padded in front).
     auto consume = [&](const StreamRec<C>& rec_j, int idx) {
         const f8 cur = rec_j.g;
-        const float a2 = cur[2], b2 = cur[3], c2 = cur[4];
+        // blend_power(a2, b2, c2, dx, dy) with its first two products as PACKED operations on the record's even-aligned SGPR
+        // pairs (x, y) and (a2, c2): v_pk_add_f32 / v_pk_mul_f32 cost one issue slot of an SGPR-operand instruction for two
+        // results.  Same operations, same roundings, same bits as blend_power() (ogs_common.h)
+        const v2f d = (v2f){cur[0], cur[1]} - (v2f){fx, fy};
+        const v2f m = (v2f){cur[2], cur[3]} * d;                     // a2 * dx, c2 * dy
+        const float u = fmaf(cur[4], d.y, m.x);                     // a2*dx + b2*dy
+        const float power = fmaf(m.y, d.y, u * d.x);
         // ONE compare |power + h| <= h decides thr <= power <= 0; a pixel whose last contributor lies in front of this
         // entry is no candidate (a second compare whose mask is ANDed on the scalar side: one VALU operation less than
         // parking the pixel far away with a select)
-        const float dx = cur[0] - fx, dy = cur[1] - fy;
-        const float power = blend_power(a2, b2, c2, dx, dy);
         const bool near = fabsf(power + cur[5]) <= cur[5], reached = idx < last_contrib;
         const bool cand = near && reached;
         // late entries of a stream find most pixels not reached yet: a wave without a single candidate skips the exp as
@@ -424,15 +429,14 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
         if (cand_mask == 0ull) return;
         // All 64 lanes run the same straight-line arithmetic (with the per-quadrant streams nearly every entry
         // has candidates, so a divergent region would save no issue slots, only cost exec-mask SALU ops and a
-        // 16-register zero fill): a lane that does not contribute gets alpha = 0 and G = 0, which leaves its
+        // 16-register zero fill): a lane that does not contribute gets alpha = 0 and opacity * G = 0, which leaves its
         // T / R* untouched and makes every one of its partial gradients exactly 0.
-        const float opac = cur[6];
-        const float Graw = __expf(power);
-        const float alpha = fminf(0.99f, opac * Graw);
+        const float oG = cur[6] * __expf(power);                   // opacity * G
+        const float alpha = fminf(0.99f, oG);
         const bool act = cand && alpha >= kAlphaMin;
         if ((__ballot(alpha >= kAlphaMin) & cand_mask) != 0ull) {   // scalar AND of two masks (a ballot of `act` goes through a VGPR)
             const float al = act ? alpha : 0.f;
-            const float G = act ? Graw : 0.f;
+            const float oGa = act ? oG : 0.f;
             // 1-ulp hardware reciprocal: the correctly rounded 1/x is a ~10-instruction sequence per entry, and the
             // T recursion is dominated by the rounding of the multiply anyway
             const float inv = __builtin_amdgcn_rcpf(1.0f - al);
@@ -456,9 +460,10 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
                 Ra += al * diff;
             }
             dL_dalpha = dL_dalpha * T - inv * tf_bg;
-            // every geometry partial carries the common factor q = opacity * G * dL/dalpha (G = 0 on idle lanes) times a
-            // polynomial of the pixel offset: the fold takes q's pixel moments, preprocess_bwd.hip does the rest
-            const float q = opac * (G * dL_dalpha);
+            // every geometry partial carries the common factor q = (opacity * G) * dL/dalpha (0 on idle lanes; the reference
+            // differentiates through the UNCLAMPED opacity * G, A.4) times a polynomial of the pixel offset: the fold takes
+            // q's pixel moments, preprocess_bwd.hip does the rest
+            const float q = oGa * dL_dalpha;
             fold.push(w, q, __float_as_uint(cur[7]), grad_rec, lane);
         }
     };
@@ -565,7 +570,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_feat_kernel(
     auto consume = [&](const StreamRec<C>& rec_j, int idx) {
         const f8 cur = rec_j.g;
         const float dx = cur[0] - fx, dy = cur[1] - fy;
-        const float power = blend_power(cur[2], cur[3], cur[4], dx, dy);
+        const float power = blend_power(cur[2], cur[4], cur[3], dx, dy);
         const bool near = fabsf(power + cur[5]) <= cur[5], reached = idx < last_contrib;   // pixels past their last contributor: no
         const bool cand = near && reached;
         const uint64_t cand_mask = __ballot(near) & __ballot(reached);
@@ -654,7 +659,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_feat_lds_kernel(
 
     auto consume = [&](const float4& r0, const float4& r1, int idx) {
         const float dx = r0.x - fx, dy = r0.y - fy;
-        const float power = blend_power(r0.z, r0.w, r1.x, dx, dy);
+        const float power = blend_power(r0.z, r1.x, r0.w, dx, dy);
         const float hh = r1.y;
         const bool near = fabsf(power + hh) <= hh, reached = idx < last_contrib;
         const bool cand = near && reached;

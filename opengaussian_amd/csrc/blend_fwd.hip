@@ -39,7 +39,9 @@ __device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d) {
 }
 
 // blend record (one per tile-list entry that reaches some quadrant, at the entry's list position):
-//   [0] x  [1] y  [2] -0.5*A  [3] -B  [4] -0.5*C  [5] h=-thr/2  [6] opacity  [7] Gaussian id (bit pattern)
+//   [0] x  [1] y  [2] -0.5*A  [3] -0.5*C  [4] -B  [5] h=-thr/2  [6] opacity  [7] Gaussian id (bit pattern)
+//   (round 4: -0.5*C moved next to -0.5*A -- (x, y) and (-A/2, -C/2) are even-aligned SGPR pairs, so the quadrant walks form the
+//   pixel offset and the two products a2*dx, c2*dy with ONE packed instruction each)
 //   [8..8+C) features  [8+C] view depth, rest zero padding to a multiple of 4 floats.
 // The depth sits right behind the features so that the (feature, feature) / (feature, depth) operand pairs of
 // the blend loops' packed FMAs are even-aligned SGPR pairs straight out of s_load (no s_mov shuffles).
@@ -121,8 +123,8 @@ __device__ __forceinline__ void pack_tile(const uint2 range, const uint32_t* __r
             const uint32_t c_loc = (uint32_t)(pos >> 48) & 0xFFFu;
             const uint32_t c_idx = running[4] + c_loc;
             float4* dst = s_rec + c_loc * SV;
-            dst[0] = make_float4(a.x, a.y, -0.5f * b.x, -b.y);
-            dst[1] = make_float4(-0.5f * b.z, h, b.w, __uint_as_float(gid_of_thread));
+            dst[0] = make_float4(a.x, a.y, -0.5f * b.x, -0.5f * b.z);
+            dst[1] = make_float4(-b.y, h, b.w, __uint_as_float(gid_of_thread));
             // features (gathered only now: 52 % of the bench scene's entries reach no quadrant), then the view
             // depth in slot C, zero padding behind it
             const float4* src = rec + (size_t)gid_of_thread * NV;
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(kBlock) void blend_forward_kernel(
     auto consume = [&](const StreamRec<C>& rec_j, int j) {
         const f8 cur = rec_j.g;
         const float dx = cur[0] - fxe, dy = cur[1] - fy;
-        const float power = blend_power(cur[2], cur[3], cur[4], dx, dy);
+        const float power = blend_power(cur[2], cur[4], cur[3], dx, dy);
         const bool cand = fabsf(power + cur[5]) <= cur[5];
         if (__ballot(cand) != 0ull) {
             bool stop = false;
@@ -378,7 +380,7 @@ __device__ __forceinline__ void blend_rows_tile(
 
     auto consume = [&](const RowRec<C>& rec, uint32_t jplus1) {
         const float dx = rec.at(0) - fxe, dy = rec.at(1) - fy;
-        const float power = blend_power(rec.at(2), rec.at(3), rec.at(4), dx, dy);
+        const float power = blend_power(rec.at(2), rec.at(4), rec.at(3), dx, dy);
         const float h = rec.at(5);
         const bool cand = fabsf(power + h) <= h;
         if (__ballot(cand) != 0ull) {
@@ -417,7 +419,7 @@ __device__ __forceinline__ void blend_rows_tile(
         bool reach[4];
         {
             const float gxp = r[0].x, gyp = r[0].y;
-            const float A = -2.f * r[0].z, B = -r[0].w, Cc = -2.f * r[1].x, thr = -2.f * r[1].y;
+            const float A = -2.f * r[0].z, B = -r[1].x, Cc = -2.f * r[0].w, thr = -2.f * r[1].y;
             const float nbA = -B / A, nbC = -B / Cc;
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
@@ -519,6 +521,260 @@ __global__ __launch_bounds__(kBlock) void pack_blend_forward_kernel(
     const int n = (int)(wave == 0 ? running[0] : wave == 1 ? running[1] : wave == 2 ? running[2] : running[3]);
     blend_rows_tile<C>(range, n, (int)running[4], reinterpret_cast<const float*>(stream), quad_list, W, H, gx, img, timg, bg, out_color,
                        out_depth, out_alpha, n_contrib, final_T, 0, *reinterpret_cast<RowsLds<C>*>(raw));
+}
+
+// ---- pack + forward blend of a tile, CHUNK BY CHUNK with a workgroup-wide exit (round 4; the default) ----------------------
+// The reference's forward fetches a tile's list 256 entries at a time and the whole block stops once every pixel is done
+// (SURVEY.md section 2.1 `renderCUDA`, Appendix A.3).  pack_blend_forward_kernel above packed the tile's ENTIRE list -- box
+// tests, 80-byte record gathers, index streams, record write-back -- before the first pixel was blended, although on a
+// ScanNet-class view (2 M Gaussians behind a 648 x 484 image, culled tile lists of ~3 000 entries) the last contributor of any
+// pixel sits at 15 % of its tile's list (scripts/list_depth_stats.py -> profiles/r04_list_depth.json; 77 % at the headline
+// workload).  Here the tile's list is taken in chunks of 256 entries:
+//     pack the chunk (pack_tile's body: quadrant box tests, block scan, kept records staged in LDS, index streams and records
+//     written out for the backward) -> barrier -> every wave blends the entries the chunk ADDED to its quadrant's stream,
+//     reading the records from the LDS staging itself -> the four waves vote; the workgroup leaves the list when every
+//     pixel of the tile is done.
+// What that changes besides the exit: the blend no longer re-reads the records it has just written (round 3: global stores,
+// then vector loads of the same lines + a wave-private LDS copy; VERDICT r3 weak 7: 2.1 x the algorithmic bytes) -- the
+// per-4x4-block walk takes them from the chunk's staging buffer, which all four waves share read-only between two barriers.
+// Per (pixel, entry) the arithmetic is blend_rows_tile's, in the same order: images, n_contrib (1-based position in the
+// quadrant stream) and final_T are bit for bit the unchunked kernels'.  qcount holds the counts AT THE EXIT: the backward
+// (which starts from n_contrib) and the n_contrib export never look past them; entries behind the exit are neither packed
+// nor written.
+template <int C>
+struct ChunkLds {
+    static constexpr int SV = stream_vec4(C);
+    uint64_t wave_tot[kBlock / kWave];
+    uint32_t done[kBlock / kWave];
+    float4 s_rec[(kBlock + 1) * SV];                       // kept records of the chunk, compact order (+ the dummy at slot kBlock)
+    uint32_t s_list[kBlock / kWave][4][kRowListLen];       // per wave and 4x4 block: entries of the current 64-entry sub-chunk
+    uint8_t s_qnew[4][kBlock];                             // per quadrant: staging slot of every entry the chunk adds to its stream
+};
+
+template <int C>
+__global__ __launch_bounds__(kBlock) void pack_blend_chunked_kernel(
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
+    float4* __restrict__ stream, uint32_t* __restrict__ quad_list, uint32_t* __restrict__ qcount, int W, int H, int gx, int tiles,
+    const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha,
+    uint32_t* __restrict__ n_contrib, float* __restrict__ final_T, const uint32_t* __restrict__ tile_order) {
+    constexpr int NV = rec_vec4(C);
+    constexpr int SV = stream_vec4(C);
+    constexpr int kListLen = kRowListLen;
+    __shared__ ChunkLds<C> lds;
+    const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
+    const int img = tile / tiles, timg = tile - img * tiles;
+    const uint2 range = ranges[tile];
+    const int n = (int)(range.y - range.x);
+    const int tx = timg % gx, ty = timg / gx;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float X0 = (float)(tx * kTile), Y0 = (float)(ty * kTile);
+    // blend side: wave = quadrant, DPP row = 4x4 block (blend_rows_tile's mapping)
+    const int row = lane >> 4, l16 = lane & 15;
+    const int qx0 = tx * kTile + (wave & 1) * 8, qy0 = ty * kTile + (wave >> 1) * 8;
+    const int px = qx0 + 4 * (row & 1) + (l16 & 3);
+    const int py = qy0 + 4 * (row >> 1) + (l16 >> 2);
+    const bool inside = px < W && py < H;
+    const float fy = (float)py;
+    float fxe = inside ? (float)px : kFar;
+    float T = 1.0f;
+    constexpr int NPF = (C + 2) / 2;
+    v2f accp[NPF];
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) accp[k] = (v2f){0.f, 0.f};
+    float wacc = 0.f;
+    uint32_t last = 0;
+    bool all_done = __ballot(inside) == 0ull;               // a quadrant outside the image has nothing to wait for
+
+    const float4* __restrict__ recs = lds.s_rec;
+    uint32_t* __restrict__ mylist = lds.s_list[wave][row];
+    if (tid == 0) {
+        // dummy record: h < 0 makes |power + h| <= h false for every pixel
+#pragma unroll
+        for (int k = 0; k < SV; ++k) lds.s_rec[kBlock * SV + k] = float4{0.f, 0.f, 0.f, 0.f};
+        lds.s_rec[kBlock * SV + 1] = float4{0.f, -1.f, 0.f, 0.f};
+    }
+
+    auto consume = [&](const RowRec<C>& r, uint32_t jplus1) {
+        const float dx = r.at(0) - fxe, dy = r.at(1) - fy;
+        const float power = blend_power(r.at(2), r.at(4), r.at(3), dx, dy);
+        const float h = r.at(5);
+        const bool cand = fabsf(power + h) <= h;
+        if (__ballot(cand) != 0ull) {
+            float alpha = fminf(0.99f, r.at(6) * __expf(power));
+            alpha = (cand && alpha >= kAlphaMin) ? alpha : 0.f;
+            const float test_T = T * (1.0f - alpha);
+            const bool stop = test_T < 0.0001f;
+            const float w = stop ? 0.f : alpha * T;
+            const v2f w2 = {w, w};
+#pragma unroll
+            for (int k = 0; k < NPF; ++k)
+                accp[k] = __builtin_elementwise_fma((v2f){r.feat(2 * k), r.feat(2 * k + 1)}, w2, accp[k]);
+            wacc += w;
+            T = stop ? T : test_T;
+            last = w > 0.f ? jplus1 : last;
+            fxe = stop ? kFar : fxe;
+            if (__ballot(stop) != 0ull) all_done = __ballot(fxe < kFarTest) == 0ull;
+        }
+    };
+
+    uint32_t running[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) running[q] = 0u;
+    const float bx0 = (float)qx0, by0 = (float)qy0;
+
+    for (int base = 0; base < n; base += kBlock) {
+        // ================= pack the chunk (pack_tile's body) =================
+        const int i = base + tid;
+        uint32_t mask = 0;
+        float4 a = make_float4(0, 0, 0, 0), b = a;
+        float h = 0.f;
+        uint32_t gid_of_thread = 0;
+        const uint32_t sv = i < n ? point_list[range.x + i] : 0u;
+        if (sv >> kReachBit) {
+            const uint32_t gid = sv & kGidMask;
+            gid_of_thread = gid;
+            const float4* src = rec + (size_t)gid * NV;
+            a = src[0]; b = src[1];
+            h = 0.5f * (__logf(255.0f * b.w) + kThrMargin);
+            const float thr = -2.0f * h;
+            const float nbA = -b.y / b.x, nbC = -b.y / b.z;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float qx = X0 + (float)((q & 1) * 8), qy = Y0 + (float)((q >> 1) * 8);
+                const float m = max_power_in_box(b.x, b.y, b.z, nbA, nbC, a.x - qx - 7.f, a.x - qx, a.y - qy - 7.f, a.y - qy);
+                if (m >= thr) mask |= 1u << q;
+            }
+        }
+        const uint64_t mine = (uint64_t)(mask & 1u) | ((uint64_t)((mask >> 1) & 1u) << 12) |
+                              ((uint64_t)((mask >> 2) & 1u) << 24) | ((uint64_t)((mask >> 3) & 1u) << 36) |
+                              ((uint64_t)(mask != 0u ? 1u : 0u) << 48);
+        uint64_t inc = mine;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const uint64_t t = shfl_up_u64(inc, d);
+            if (lane >= d) inc += t;
+        }
+        if (lane == kWave - 1) lds.wave_tot[wave] = inc;
+        __syncthreads();                    // (1) wave totals; also: every wave has left the previous chunk's blend
+        uint64_t before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / kWave; ++w) {
+            const uint64_t t = lds.wave_tot[w];
+            if (w < wave) before += t;
+            total += t;
+        }
+        const uint64_t pos = before + inc - mine;
+        if (mask) {
+            const uint32_t c_loc = (uint32_t)(pos >> 48) & 0xFFFu;
+            const uint32_t c_idx = running[4] + c_loc;
+            float4* dst = lds.s_rec + c_loc * SV;
+            dst[0] = make_float4(a.x, a.y, -0.5f * b.x, -0.5f * b.z);
+            dst[1] = make_float4(-b.y, h, b.w, __uint_as_float(gid_of_thread));
+            const float4* src = rec + (size_t)gid_of_thread * NV;
+            float f[(SV - 2) * 4];
+#pragma unroll
+            for (int k = 0; k < (SV - 2) * 4; ++k) f[k] = 0.f;
+#pragma unroll
+            for (int v = 0; v < NV - 2; ++v) {
+                const float4 t = src[2 + v];
+                f[4 * v] = t.x; f[4 * v + 1] = t.y; f[4 * v + 2] = t.z; f[4 * v + 3] = t.w;
+            }
+            f[C] = a.z;
+#pragma unroll
+            for (int v = 0; v < SV - 2; ++v) dst[2 + v] = make_float4(f[4 * v], f[4 * v + 1], f[4 * v + 2], f[4 * v + 3]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (mask & (1u << q)) {
+                    const uint32_t pq = (uint32_t)(pos >> (12 * q)) & 0xFFFu;
+                    quad_list[(size_t)range.x * 5 + (size_t)q * n + running[q] + pq] = c_idx;      // for the backward
+                    lds.s_qnew[q][pq] = (uint8_t)c_loc;                                            // for this chunk's blend
+                }
+            }
+            quad_list[(size_t)range.x * 5 + (size_t)4 * n + c_idx] = (uint32_t)i;
+        }
+        __syncthreads();                    // (2) the chunk's records and stream entries are staged
+        {
+            // record write-out for the backward: one contiguous range, the whole workgroup (stores only: nothing waits for them)
+            const int kept4 = (int)((uint32_t)(total >> 48) & 0xFFFu) * SV;
+            float4* __restrict__ out = stream + ((size_t)range.x + (size_t)running[4]) * SV;
+            for (int e = tid; e < kept4; e += kBlock) out[e] = lds.s_rec[e];
+        }
+        // ================= blend what the chunk added to this wave's quadrant stream =================
+        const int cnt_q = (int)((uint32_t)(total >> (12 * wave)) & 0xFFFu);
+        const uint32_t j0 = wave == 0 ? running[0] : wave == 1 ? running[1] : wave == 2 ? running[2] : running[3];
+        for (int c0 = 0; c0 < cnt_q && !all_done; c0 += kWave) {
+            const int cnt = min(kWave, cnt_q - c0);
+            const bool have = lane < cnt;
+            const uint32_t cl = have ? (uint32_t)lds.s_qnew[wave][c0 + lane] : (uint32_t)kBlock;
+            const float4 r0 = recs[cl * SV], r1 = recs[cl * SV + 1];
+            bool reach[4];
+            {
+                const float gxp = r0.x, gyp = r0.y;
+                const float A = -2.f * r0.z, B = -r1.x, Cc = -2.f * r0.w, thr = -2.f * r1.y;
+                const float nbA = -B / A, nbC = -B / Cc;
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    const float ox = bx0 + 4.f * (float)(bb & 1), oy = by0 + 4.f * (float)(bb >> 1);
+                    const float m = max_power_in_box(A, B, Cc, nbA, nbC, gxp - ox - 3.f, gxp - ox, gyp - oy - 3.f, gyp - oy);
+                    reach[bb] = have && m >= thr;
+                }
+            }
+            // list entry = sub-chunk slot << 16 | byte offset of the record in the staging buffer
+            constexpr uint32_t kDummy = (64u << 16) | ((uint32_t)kBlock * SV * 16u);
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) lds.s_list[wave][bb][lane] = kDummy;
+            if (lane < kListLen - kWave) {
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) lds.s_list[wave][bb][kWave + lane] = kDummy;
+            }
+            int maxlen = 0;
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                const uint64_t m64 = __ballot(reach[bb]);
+                const int p = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m64 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m64, 0u));
+                if (reach[bb]) lds.s_list[wave][bb][p] = ((uint32_t)lane << 16) | (cl * SV * 16u);
+                maxlen = max(maxlen, (int)__popcll(m64));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            RowRec<C> ra, rb;
+            auto rec_of = [&](uint32_t e) {
+                return reinterpret_cast<const float4*>(reinterpret_cast<const char*>(recs) + (e & 0xFFFFu));
+            };
+            uint32_t e0 = mylist[0], e1 = mylist[1];
+            ra.load_lds(rec_of(e0));
+            const uint32_t jbase = j0 + (uint32_t)c0 + 1u;
+            for (int t = 0; t < maxlen && !all_done; t += 2) {
+                const uint32_t e2 = mylist[t + 2], e3 = mylist[t + 3];
+                rb.load_lds(rec_of(e1));
+                consume(ra, jbase + (e0 >> 16));
+                ra.load_lds(rec_of(e2));
+                if (t + 1 < maxlen) consume(rb, jbase + (e1 >> 16));
+                e0 = e2; e1 = e3;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int q = 0; q < 5; ++q) running[q] += (uint32_t)(total >> (12 * q)) & 0xFFFu;
+        if (lane == 0) lds.done[wave] = all_done ? 1u : 0u;
+        __syncthreads();                    // (3) the staging buffer is free again; the four votes are in
+        if ((lds.done[0] & lds.done[1] & lds.done[2] & lds.done[3]) != 0u) break;       // block-uniform
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) qcount[tile * 5 + q] = running[q];
+    }
+    if (inside) {
+        const size_t plane = (size_t)W * H;
+        const size_t pix = (size_t)img * plane + (size_t)py * W + px;
+        float* oc = out_color + (size_t)img * (C - 1) * plane;
+#pragma unroll
+        for (int c = 0; c < C; ++c) oc[c * plane + pix] = ((c & 1) ? accp[c / 2].y : accp[c / 2].x) + T * bg[c];
+        out_depth[pix] = (C & 1) ? accp[C / 2].y : accp[C / 2].x;
+        out_alpha[pix] = wacc;
+        n_contrib[pix] = last;
+        final_T[pix] = T;
+    }
 }
 
 // test/diagnostic export: translate the per-quadrant stream index kept in n_contrib back to the reference's
@@ -779,9 +1035,10 @@ static bool blend_rows_enabled() {
     return v;
 }
 
-// pack and forward blend of a tile in one workgroup (pack_blend_forward_kernel); OGS_PACK_FUSED=0: two launches
-static bool pack_fused_enabled() {
-    static const bool v = [] { const char* e = getenv("OGS_PACK_FUSED"); return !(e && atoi(e) == 0); }();
+// pack and forward blend of a tile in one workgroup: chunk by chunk with a workgroup-wide exit (pack_blend_chunked_kernel, the
+// default); OGS_PACK_FUSED=2: the whole list packed first (pack_blend_forward_kernel, round 3); OGS_PACK_FUSED=0: two launches
+static int pack_fused_mode() {
+    static const int v = [] { const char* e = getenv("OGS_PACK_FUSED"); return e ? atoi(e) : 1; }();
     return v;
 }
 
@@ -791,7 +1048,17 @@ int launch_c(const OgsRasterFwdArgs& a, const GeomState& gs, const ImageState& i
     const int tiles = gx * gy;
     const unsigned vtiles = (unsigned)tiles * (unsigned)num_groups_of(a.num_groups);
     const uint32_t* order = D > 0 ? launch_tile_order(is, vtiles, a.P, s, a.debug) : nullptr;
-    if (D > 0 && blend_rows_enabled() && pack_fused_enabled()) {
+    if (D > 0 && blend_rows_enabled() && pack_fused_mode() == 1) {
+        static constexpr const char* const kChunked[4] = {"pack_blend_chunked_kernel<3>", "pack_blend_chunked_kernel<6>",
+                                                          "pack_blend_chunked_kernel<9>", "pack_blend_chunked_kernel<12>"};
+        OGS_LAUNCH_NAMED(chan_name<C>(kChunked), pack_blend_chunked_kernel<C>, dim3(vtiles), dim3(kBlock), 0, s,
+                         (const uint2*)is.ranges, (const uint32_t*)a.point_list, (const float4*)gs.rec, stream_base<C>(a.sorted_rec),
+                         quad_base(a.quad_list), is.qcount, a.W, a.H, gx, tiles, a.bg, a.out_color, a.out_depth, a.out_alpha,
+                         is.n_contrib, is.final_T, order);
+        OGS_LAUNCH_CHECK(a.debug, s);
+        return OGS_OK;
+    }
+    if (D > 0 && blend_rows_enabled() && pack_fused_mode() != 0) {
         static constexpr const char* const kFused[4] = {"pack_blend_forward_kernel<3>", "pack_blend_forward_kernel<6>",
                                                         "pack_blend_forward_kernel<9>", "pack_blend_forward_kernel<12>"};
         OGS_LAUNCH_NAMED(chan_name<C>(kFused), pack_blend_forward_kernel<C>, dim3(vtiles), dim3(kBlock), 0, s,

@@ -48,6 +48,8 @@ READ_PATTERN = {
     "blend_backward_kernel": ("SCALAR loads of the record stream + line touches + per-pixel 4-byte loads; writes are fp64 atomics", False),
     "blend_backward_feat_kernel": ("SCALAR loads of the record stream + line touches; writes are fp64 atomics", False),
     "blend_backward_feat_lds_kernel": ("per-lane 16-byte gathers of the records' geometry halves + line touches; writes are fp64 atomics", False),
+    "pack_blend_chunked_kernel": ("pack's 4-byte point-list stream + 32 / 48-byte record gathers by sorted id (per-lane, random); the records are "
+                                  "blended from LDS, the compacted copy and the index streams are written once for the backward", True),
     "pack_blend_forward_kernel": ("pack's 4-byte point-list stream + 32 / 48-byte record gathers by sorted id, then per-lane 16-byte gathers "
                                   "of the records the workgroup just wrote (L2 / L1 resident)", True),
 }
@@ -133,7 +135,7 @@ def main():
     print("kernel stats (top 6):")
     for r in rows[:6]:
         print("  %-60s calls %4d avg %9.1f us" % ((short(r[0]) or r[0][:60]), r[1], r[3]))
-    for k in ("blend_backward_kernel<9>", "pack_blend_forward_kernel<9>"):
+    for k in ("blend_backward_kernel<9>", "pack_blend_chunked_kernel<9>"):
         print(k, "HBM MB/launch", round(traffic.get(k, 0) / 1e6, 1), {c: round(v) for c, v in sq.get(k, {}).items() if c.startswith("SQ_INSTS")})
 
 

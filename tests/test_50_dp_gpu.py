@@ -368,6 +368,38 @@ def test_bench_self_launches_two_ranks(gpu_device):
     modes = d["ms_per_step_by_exchange_mode"]
     assert set(modes) == {"pipelined", "sync", "none"} and all(v > 0 for v in modes.values())
     assert d["exposed_exchange_ms_per_step"] is not None
+    # round 4: every collective of the exchange timed ALONE, and the stage-1 step (features-only backward,
+    # ins_feat all-reduce) as an untimed extra of the same command
+    ca = d["collectives_alone"]
+    assert {"grad_bucket_sum_allreduce", "sh_factor_allgather", "sh_rebuild_kernel", "radii_max_allreduce",
+            "stage1_ins_feat_sum_allreduce"} <= set(ca), ca
+    assert all(v["ms"] > 0 for v in ca.values())
+    assert ca["stage1_ins_feat_sum_allreduce"]["bytes"] == 100_000 * 24
+    s1 = d["stage1"]
+    assert s1["ms_per_step"] > 0 and s1["exchange_bytes_per_step_per_rank"] == 100_000 * 24
+
+
+def test_bench_stage1_switch_two_ranks(gpu_device):
+    """`bench.py --gpus 2 --stage1`: the TIMED step is the stage-1 training step (everything but ins_feat detached,
+    train.py:431-436: fused forward, features-only backward, one SUM all-reduce of dL/d ins_feat); the all-gradient step then
+    comes as the untimed extra.  Two ranks over gloo on the one-GPU box."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OGS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "OGS_DP_FORCE_COLLECTIVES"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--stage1",
+           "--workload", "C2-100k-800", "--no-cpu-baseline", "--no-kmeans"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and "STAGE-1" in out["config"]["workload"]
+    d = out["dist"]
+    assert d["exchange_bytes_per_step_per_rank"] == 100_000 * 24
+    assert "blend_backward_feat" in out["roofline"]["kernel"] or "pack_blend" in out["roofline"]["kernel"], out["roofline"]
+    assert d["stage0_all_gradient_step"]["ms_per_step"] > 0
 
 
 # ---- densification on the sharded optimizer state (SURVEY.md section 8 f2, scene/gaussian_model.py:357-510) -----------
