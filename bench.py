@@ -223,8 +223,8 @@ def kmeans_leaf_bench(device):
     N = 2 M / k1 = 64 workload, ALL 64 leaf assignments -- Quantize_kMeans.cluster_assign(mode="leaf", selected_leaf=c) for
     c = 0..63, k2 = 5 (scripts/train_scannet.sh:42-43), d = 6, 5 Lloyd iterations each on the ~31 k points of coarse cluster
     c (scene/kmeans_quantize.py:195-206,232-240; train.py:321-330 calls one of them every 50 iterations of stage 2.2).
-    Reported: Lloyd it/s over the 64 calls, ms per leaf assign, and the share of that time spent in equalize_cluster_size
-    (the per-call index-table rebuild, scene/kmeans_quantize.py:89-144), measured by running the same calls without it."""
+    Reported: Lloyd it/s over the 64 calls, ms per leaf assign, and what the reference's per-call rebuild of
+    equalize_cluster_size's index table (scene/kmeans_quantize.py:89-144) would add (the table is lazy here)."""
     from opengaussian_amd.kmeans import Quantize_kMeans
     g = torch.Generator().manual_seed(0)
     N, k1, k2, iters = 2_000_000, 64, 5, 5
@@ -234,33 +234,32 @@ def kmeans_leaf_bench(device):
     q.cluster_assign(torch.cat([feat6, xyz], dim=1), mode="root")
     q.iLeafSubNum = torch.full((k1,), k2, dtype=torch.int64, device=device)
 
-    def sweep():
+    def sweep(eager=False):
         for c in range(k1):
             q.cluster_assign(feat6, mode="leaf", selected_leaf=c)
+            if eager:
+                q.cluster_ids                 # forces the padded index table, as the reference rebuilds it on every assign
     sweep()                                   # warm-up: leaf centres initialised, allocator warm
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     sweep()
     torch.cuda.synchronize()
-    t_full = time.perf_counter() - t0
-    keep = q.equalize_cluster_size
-    q.equalize_cluster_size = lambda mode="root": None
-    try:
-        sweep()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        sweep()
-        torch.cuda.synchronize()
-        t_core = time.perf_counter() - t0
-    finally:
-        q.equalize_cluster_size = keep
+    t_lazy = time.perf_counter() - t0
+    sweep(eager=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sweep(eager=True)
+    torch.cuda.synchronize()
+    t_eager = time.perf_counter() - t0
     pts = [int((q.cls_ids == c).sum()) for c in (0, k1 // 2, k1 - 1)]
     return {"leaf_assigns": k1, "k2": k2, "d": 6, "iters_per_assign": iters, "points_per_coarse_cluster_sample": pts,
-            "ms_per_leaf_assign": t_full / k1 * 1e3, "it_per_s": k1 * iters / t_full,
-            "ms_per_leaf_assign_without_equalize": t_core / k1 * 1e3,
-            "equalize_cluster_size_share": max(0.0, 1.0 - t_core / t_full),
-            "note": "host-paced: a leaf assign is ~10 launches on ~31 k rows plus the boolean-index gather / scatter of the "
-                    "coarse cluster's points (as the reference does)"}
+            "ms_per_leaf_assign": t_lazy / k1 * 1e3, "it_per_s": k1 * iters / t_lazy,
+            "ms_per_leaf_assign_with_eager_index_table": t_eager / k1 * 1e3,
+            "equalize_cluster_size_share_when_eager": max(0.0, 1.0 - t_lazy / t_eager),
+            "note": "equalize_cluster_size's padded index table (scene/kmeans_quantize.py:89-144: rebuilt over all N points on "
+                    "every assign, read by nothing in the training loop) is built lazily on first access; the eager figure forces "
+                    "it after every assign.  A leaf assign is ~10 launches on ~31 k rows plus the boolean-index gather / scatter "
+                    "of the coarse cluster's points (as the reference does): host-paced"}
 
 
 def kmeans_cpu_baseline():
@@ -335,6 +334,7 @@ def extra_workloads(args):
                         "kernel_sum_ms": sum(d["kernels_ms_per_step"].values()),
                         "D_num_rendered": d["scene"]["D_num_rendered"], "mean_tile_list": d["scene"]["mean_tile_list"],
                         "roofline": d["roofline"], "step_algorithmic_GBps": d["step_algorithmic_GBps"],
+                        "kernels_ms_per_step": d["kernels_ms_per_step"],
                         "stage1_ms_per_step": (d.get("stage1_pass") or {}).get("ms_per_step"),
                         "render_phase_sizing_timed": d["render_phase_sizing_timed"]}
         except Exception as e:          # an extra line never takes the headline down
@@ -787,10 +787,11 @@ def main():
         # profiles/ together with the kernel version they were taken on; they are attached only when that version
         # is the library's (ogs_version()) and the workload is the one profiled.
         traffic, traffic_src, hbm_kernels, valu = None, None, None, None
-        pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json" if args.workload == "S1M-1080p"
+                                else f"pmc_traffic_{args.workload}.json")
         sq_file = os.path.join(ROOT, "profiles", "sq_valu.json")
         libver = int(_lib.lib().ogs_version())
-        profiled = args.workload == "S1M-1080p" and fused and args.views == 8
+        profiled = fused and args.views == 8 and not args.stage1
         if os.path.exists(pmc_file) and profiled:
             try:
                 pmc = json.load(open(pmc_file))
@@ -803,7 +804,7 @@ def main():
                                    for k, v in per_kernel.items() if k in pmc and v["avg_ms"] > 0}
             except Exception:
                 traffic, hbm_kernels = None, None
-        if os.path.exists(sq_file) and profiled:
+        if os.path.exists(sq_file) and profiled and args.workload == "S1M-1080p":
             try:
                 sq = json.load(open(sq_file))
                 if int(sq.get("_ogs_version", -1)) == libver and dom in sq:

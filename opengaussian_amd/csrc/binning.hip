@@ -132,20 +132,10 @@ constexpr int kFlatScanBlocks = 16384;   // up to 33.5 M elements scan in two la
 // for a capacity n_cap and has not read the true count back yet); workgroups past the true count see no elements.
 // ITEMS keys per thread: 16 for the long (Gaussian, tile) lists; 4 for the P-sized depth sort, whose 16-key
 // version is only ~1 workgroup per CU and therefore latency-bound (19 us per 8 MB pass).
-// Round 4: no row-scan launch between the histogram and the scatter any more.  The histogram kernel also adds every count into
-// a COARSE table -- coarse[d][b / 32], the digit's count over a group of 32 workgroups (one global atomic per non-zero count,
-// 32-way contention at most) -- and a scatter workgroup builds its own prefix: the coarse sums of the groups before its own
-// (<= nblocks / 32 loads per digit, which also give the digit's total over all workgroups) plus the raw counts of the
-// workgroups before it inside its group (<= 31 loads): ~90 independent L2-resident loads per thread issued at the top of the
-// kernel, under the key loads, instead of a dependent launch of 5-7 us per pass (six per step).  Integer sums: bit-identical.
-constexpr int kCoarseShift = 5;
-inline int coarse_groups(int nblocks) { return (nblocks + (1 << kCoarseShift) - 1) >> kCoarseShift; }
-
 template <int ITEMS>
 __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const uint32_t* __restrict__ keys, int64_t n_cap,
                                                             const uint32_t* __restrict__ n_dev, int shift,
-                                                            int bits, uint32_t* __restrict__ hist, int nblocks, bool drop,
-                                                            uint32_t* __restrict__ coarse /*[256][ncoarse], zeroed*/, int ncoarse) {
+                                                            int bits, uint32_t* __restrict__ hist, int nblocks, bool drop) {
     __shared__ uint32_t h[256];
     const int64_t n = n_dev ? min((int64_t)*n_dev, n_cap) : n_cap;
     const int ndig = 1 << bits;
@@ -162,11 +152,38 @@ __global__ __launch_bounds__(kBlock) void radix_hist_kernel(const uint32_t* __re
         }
     }
     __syncthreads();
-    if ((int)threadIdx.x < ndig) {
-        const uint32_t c = h[threadIdx.x];
-        hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = c;
-        if (c != 0u) atomicAdd(&coarse[(size_t)threadIdx.x * ncoarse + (blockIdx.x >> kCoarseShift)], c);
+    if ((int)threadIdx.x < ndig) hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+// In-place exclusive scan of every digit row hist[d][0..nblocks) (one workgroup per digit) + the row totals.
+// The scatter kernel adds the exclusive prefix over the row totals itself (<= 256 values), which replaces the
+// 3-launch global scan of the ndig*nblocks table by this single launch.
+__global__ __launch_bounds__(kBlock) void radix_rowscan_kernel(uint32_t* __restrict__ hist, int nblocks,
+                                                               uint32_t* __restrict__ row_total) {
+    __shared__ uint32_t wave_sums[4];
+    uint32_t* row = hist + (size_t)blockIdx.x * nblocks;
+    uint32_t carry = 0;
+    for (int base = 0; base < nblocks; base += kScanTile) {
+        uint32_t item[kScanItems];
+        // thread t owns items t, t+256, ... of this chunk?  No: consecutive items per thread keep the scan a
+        // simple (thread-sum, block-scan, thread-walk); rows are a few KB and stay in L2, so coalescing is moot.
+        const int b0 = base + (int)threadIdx.x * kScanItems;
+        uint32_t sum = 0;
+#pragma unroll
+        for (int i = 0; i < kScanItems; ++i) {
+            item[i] = (b0 + i < nblocks) ? row[b0 + i] : 0u;
+            sum += item[i];
+        }
+        uint32_t total;
+        uint32_t run = carry + block_exclusive_scan(sum, total, wave_sums);
+#pragma unroll
+        for (int i = 0; i < kScanItems; ++i) {
+            if (b0 + i < nblocks) row[b0 + i] = run;
+            run += item[i];
+        }
+        carry += total;
     }
+    if (threadIdx.x == 0) row_total[blockIdx.x] = carry;
 }
 
 template <int ITEMS>
@@ -175,8 +192,8 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint32_t* _
                                                                uint32_t* __restrict__ keys_out,
                                                                uint32_t* __restrict__ vals_out, int64_t n_cap,
                                                                const uint32_t* __restrict__ n_dev, int shift,
-                                                               int bits, const uint32_t* __restrict__ hist /*raw counts*/,
-                                                               const uint32_t* __restrict__ coarse, int ncoarse,
+                                                               int bits, const uint32_t* __restrict__ offsets,
+                                                               const uint32_t* __restrict__ row_total,
                                                                int nblocks, bool drop, uint32_t* __restrict__ kept_out) {
     __shared__ uint32_t wave_hist_s[kBlock / kWave][256];
     __shared__ uint32_t scan_sums[4];
@@ -189,29 +206,6 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint32_t* _
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int w = 0; w < kBlock / kWave; ++w) wave_hist_s[w][tid] = 0;
-    // digit `tid`: its count over ALL workgroups (dig_total) and over the workgroups before this one (dig_before), from the
-    // coarse sums + the raw counts of this workgroup's group -- independent loads, in flight under the key loads below
-    uint32_t dig_total = 0, dig_before = 0;
-    if (tid < ndig) {
-        const uint32_t* __restrict__ cr = coarse + (size_t)tid * ncoarse;
-        const int gb = (int)(blockIdx.x >> kCoarseShift);
-        int g = 0;
-        for (; g + 8 <= ncoarse; g += 8) {
-            uint32_t v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = cr[g + u];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { dig_total += v[u]; dig_before += (g + u < gb) ? v[u] : 0u; }
-        }
-        for (; g < ncoarse; ++g) { const uint32_t v = cr[g]; dig_total += v; dig_before += g < gb ? v : 0u; }
-        const uint32_t* __restrict__ hr = hist + (size_t)tid * nblocks + ((size_t)gb << kCoarseShift);
-        const int inner = (int)(blockIdx.x & ((1u << kCoarseShift) - 1u));
-        uint32_t v[32];
-#pragma unroll
-        for (int u = 0; u < 32; ++u) v[u] = u < inner ? hr[u] : 0u;
-#pragma unroll
-        for (int u = 0; u < 32; ++u) dig_before += v[u];
-    }
     __syncthreads();
 
     // each wave owns a contiguous run of ITEMS*64 keys; item i = 64 consecutive keys, so
@@ -262,11 +256,11 @@ __global__ __launch_bounds__(kBlock) void radix_scatter_kernel(const uint32_t* _
     const uint32_t local_start = block_exclusive_scan(run_len, n_valid, scan_sums);
     // ... and its global start: sum of the totals of all smaller digits + this digit's prefix over workgroups
     uint32_t dummy_total;
-    const uint32_t digit_base = block_exclusive_scan(dig_total, dummy_total, scan_sums);
+    const uint32_t digit_base = block_exclusive_scan(tid < ndig ? row_total[tid] : 0u, dummy_total, scan_sums);
     if (kept_out != nullptr && blockIdx.x == 0 && tid == 0) *kept_out = dummy_total;     // keys that survive this pass (drop)
     if (tid < ndig) {
         dig_start[tid] = local_start;
-        glob_base[tid] = digit_base + dig_before - local_start;
+        glob_base[tid] = digit_base + offsets[(size_t)tid * nblocks + blockIdx.x] - local_start;
     }
     __syncthreads();
 #pragma unroll
@@ -541,10 +535,8 @@ size_t scan_tmp_bytes(int64_t n) {
 
 size_t sort_tmp_bytes(int64_t n) {
     const int64_t hist = (int64_t)256 * sort_blocks_for(n > 0 ? n : 1);
-    // three-... now TWO-launch pass: histogram table + four coarse tables (one per pass of a sort, zeroed together by
-    // radix_legacy_begin); the whole scratch is also what exclusive_scan_u32 callers borrow once the sort is done
-    const size_t legacy = align_up((size_t)hist * sizeof(uint32_t)) +
-                          4 * align_up((size_t)256 * coarse_groups((int)(hist / 256)) * sizeof(uint32_t)) + scan_tmp_bytes(hist);
+    // legacy pass: histogram table + 256 row totals; the tail is also what exclusive_scan_u32 callers borrow as scan scratch
+    const size_t legacy = align_up((size_t)hist * sizeof(uint32_t)) + align_up(256 * sizeof(uint32_t)) + scan_tmp_bytes(hist);
     // one-launch passes: [header: 4 x 256 digit histograms | 4 tickets | error word][4 status tables of `hist` words]
     const int64_t tiles4 = ((n > 0 ? n : 1) + kBlock * 4 - 1) / (kBlock * 4);            // the smaller tile size: upper bound
     const size_t sweep = align_up(kSweepHeaderWords * sizeof(uint32_t)) + 4 * align_up((size_t)256 * tiles4 * sizeof(uint32_t));
@@ -678,62 +670,32 @@ int exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out
     return OGS_OK;
 }
 
-// Start of a sort of up to four two-launch passes on n (capacity) keys: zeroes the coarse tables of all its passes (ONE memset).
-namespace {
-struct LegacyTmp {
-    uint32_t* hist;
-    uint32_t* coarse[4];
-    int nb, ncoarse;
-    size_t coarse_bytes_all;
-    static LegacyTmp carve(void* tmp, int64_t n) {
-        LegacyTmp t;
-        t.nb = sort_blocks_for(n);
-        t.ncoarse = coarse_groups(t.nb);
-        char* p = static_cast<char*>(tmp);
-        t.hist = reinterpret_cast<uint32_t*>(p);
-        const size_t one = align_up((size_t)256 * t.ncoarse * sizeof(uint32_t));
-        char* q = p + align_up((size_t)256 * t.nb * sizeof(uint32_t));
-        for (int i = 0; i < 4; ++i) t.coarse[i] = reinterpret_cast<uint32_t*>(q + (size_t)i * one);
-        t.coarse_bytes_all = 4 * one;
-        return t;
-    }
-};
-}  // namespace
-
-int radix_legacy_begin(int64_t n, int npass, void* tmp, hipStream_t stream) {
-    if (n <= 0) return OGS_OK;
-    if (npass < 1 || npass > 4) { set_error("radix_legacy_begin: npass=%d out of range", npass); return OGS_ERR_INVALID_ARG; }
-    const LegacyTmp t = LegacyTmp::carve(tmp, n);
-    OGS_HIP_CHECK(hipMemsetAsync(t.coarse[0], 0, t.coarse_bytes_all / 4 * (size_t)npass, stream));
-    return OGS_OK;
-}
-
 // n is the element count, or -- when n_dev != nullptr -- the CAPACITY the launch is sized for while the true
-// count (<= capacity after clamping) is read from device memory by the kernels.  `pass` (0..3): which of the coarse tables
-// radix_legacy_begin zeroed this pass uses.
-int radix_pass(int pass, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, int64_t n,
+// count (<= capacity after clamping) is read from device memory by the kernels.
+int radix_pass(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out, int64_t n,
                int shift, int bits, void* tmp, hipStream_t stream, int debug, const uint32_t* n_dev, bool drop,
                uint32_t* kept_out) {
     if (n <= 0) return OGS_OK;
     if (bits < 1 || bits > 8) { set_error("radix_pass: bits=%d out of range", bits); return OGS_ERR_INVALID_ARG; }
-    if (pass < 0 || pass > 3) { set_error("radix_pass: pass=%d out of range", pass); return OGS_ERR_INVALID_ARG; }
     const int items = sort_items_for(n);
-    const LegacyTmp t = LegacyTmp::carve(tmp, n);
-    const int nb = t.nb;
+    const int nb = sort_blocks_for(n);
+    const int ndig = 1 << bits;
+    uint32_t* hist = static_cast<uint32_t*>(tmp);
+    uint32_t* row_total = reinterpret_cast<uint32_t*>(static_cast<char*>(tmp) + align_up((size_t)256 * nb * sizeof(uint32_t)));
     if (items == 4) {
-        OGS_LAUNCH(radix_hist_kernel<4>, dim3(nb), dim3(kBlock), 0, stream, keys_in, n, n_dev, shift, bits, t.hist, nb, drop,
-                   t.coarse[pass], t.ncoarse);
+        OGS_LAUNCH(radix_hist_kernel<4>, dim3(nb), dim3(kBlock), 0, stream, keys_in, n, n_dev, shift, bits, hist, nb, drop);
     } else {
-        OGS_LAUNCH(radix_hist_kernel<16>, dim3(nb), dim3(kBlock), 0, stream, keys_in, n, n_dev, shift, bits, t.hist, nb, drop,
-                   t.coarse[pass], t.ncoarse);
+        OGS_LAUNCH(radix_hist_kernel<16>, dim3(nb), dim3(kBlock), 0, stream, keys_in, n, n_dev, shift, bits, hist, nb, drop);
     }
+    OGS_LAUNCH_CHECK(debug, stream);
+    OGS_LAUNCH(radix_rowscan_kernel, dim3(ndig), dim3(kBlock), 0, stream, hist, nb, row_total);
     OGS_LAUNCH_CHECK(debug, stream);
     if (items == 4) {
         OGS_LAUNCH(radix_scatter_kernel<4>, dim3(nb), dim3(kBlock), 0, stream, keys_in, vals_in, keys_out, vals_out, n, n_dev,
-                   shift, bits, (const uint32_t*)t.hist, (const uint32_t*)t.coarse[pass], t.ncoarse, nb, drop, kept_out);
+                   shift, bits, (const uint32_t*)hist, (const uint32_t*)row_total, nb, drop, kept_out);
     } else {
         OGS_LAUNCH(radix_scatter_kernel<16>, dim3(nb), dim3(kBlock), 0, stream, keys_in, vals_in, keys_out, vals_out, n, n_dev,
-                   shift, bits, (const uint32_t*)t.hist, (const uint32_t*)t.coarse[pass], t.ncoarse, nb, drop, kept_out);
+                   shift, bits, (const uint32_t*)hist, (const uint32_t*)row_total, nb, drop, kept_out);
     }
     OGS_LAUNCH_CHECK(debug, stream);
     return OGS_OK;

@@ -237,14 +237,12 @@ int ogs_raster_forward_geometry(const OgsRasterFwdArgs* a, void* stream_, int64_
         if (sweep) {
             const int shifts[4] = {0, 8, 16, 24}, nbits[4] = {8, 8, 8, 8};
             rc = radix_sort_begin(gt.keys[0], a->P, nullptr, 4, shifts, nbits, gt.sort_tmp, s, a->debug);
-        } else {
-            rc = radix_legacy_begin(a->P, 4, gt.sort_tmp, s);
+            if (rc != OGS_OK) return rc;
         }
-        if (rc != OGS_OK) return rc;
         for (int pass = 0; pass < 4; ++pass) {
             const int in = pass & 1, out = in ^ 1;
             rc = sweep ? radix_sort_pass(pass, 4, gt.keys[in], gt.order[in], gt.keys[out], gt.order[out], a->P, 8 * pass, 8, gt.sort_tmp, s, a->debug)
-                       : radix_pass(pass, gt.keys[in], gt.order[in], gt.keys[out], gt.order[out], a->P, 8 * pass, 8, gt.sort_tmp, s, a->debug);
+                       : radix_pass(gt.keys[in], gt.order[in], gt.keys[out], gt.order[out], a->P, 8 * pass, 8, gt.sort_tmp, s, a->debug);
             if (rc != OGS_OK) return rc;
         }
         // offsets[r] = exclusive scan of tiles_touched in depth order; total = num_rendered
@@ -320,16 +318,17 @@ static int render_impl(const OgsRasterFwdArgs* a, int64_t D, bool deferred, hipS
             // the drop (13 bits: 6 + 7 instead of 7 + 6, a few us on the scatters)
             nbits[0] = bits / 2; shifts[1] = nbits[0]; nbits[1] = bits - nbits[0];
         }
-        rc = sweep ? radix_sort_begin(bt.tile_keys[0], D, n_dev, passes, shifts, nbits, bt.sort_tmp, s, a->debug, cull)
-                   : radix_legacy_begin(D, passes, bt.sort_tmp, s);
-        if (rc != OGS_OK) return rc;
+        if (sweep) {
+            rc = radix_sort_begin(bt.tile_keys[0], D, n_dev, passes, shifts, nbits, bt.sort_tmp, s, a->debug, cull);
+            if (rc != OGS_OK) return rc;
+        }
         for (int p = 0; p < passes; ++p) {
             const int in = p & 1, out = in ^ 1;
             const bool drop = cull && p == 0;
             // launches stay sized for D (the host does not know the kept count); workgroups past it find nothing to do
             const uint32_t* n_pass = (cull && p > 0) ? bt.kept : n_dev;
             rc = sweep ? radix_sort_pass(p, passes, bt.tile_keys[in], vbuf[in], bt.tile_keys[out], vbuf[out], D, shifts[p], nbits[p], bt.sort_tmp, s, a->debug, n_pass, drop, drop ? bt.kept : nullptr)
-                       : radix_pass(p, bt.tile_keys[in], vbuf[in], bt.tile_keys[out], vbuf[out], D, shifts[p], nbits[p], bt.sort_tmp, s, a->debug, n_pass, drop, drop ? bt.kept : nullptr);
+                       : radix_pass(bt.tile_keys[in], vbuf[in], bt.tile_keys[out], vbuf[out], D, shifts[p], nbits[p], bt.sort_tmp, s, a->debug, n_pass, drop, drop ? bt.kept : nullptr);
             if (rc != OGS_OK) return rc;
         }
         rc = launch_tile_ranges(bt.tile_keys[passes & 1], D, is.ranges, tiles, s, a->debug, cull ? bt.kept : n_dev, zero_in_dup);
@@ -459,13 +458,13 @@ int ogs_selftest_radix_sort(uint32_t* keys0, uint32_t* vals0, uint32_t* keys1, u
         OGS_HIP_CHECK(hipMemsetAsync(kept, 0xA5, sizeof(uint32_t), s));
     }
     int rc = OGS_OK;
-    rc = sweep ? radix_sort_begin(k[0], n, n_dev, passes, shifts, nbits, tmp, s, 0, drop, items) : radix_legacy_begin(n, passes, tmp, s);
+    if (sweep) rc = radix_sort_begin(k[0], n, n_dev, passes, shifts, nbits, tmp, s, 0, drop, items);
     for (int p = 0; p < passes && rc == OGS_OK; ++p) {
         const int in = p & 1, out = in ^ 1;
         const bool d0 = drop && p == 0;
         const uint32_t* n_pass = (drop && p > 0) ? kept : n_dev;
         rc = sweep ? radix_sort_pass(p, passes, k[in], v[in], k[out], v[out], n, shifts[p], nbits[p], tmp, s, 0, n_pass, d0, d0 ? kept : nullptr, items, spin_limit)
-                   : radix_pass(p, k[in], v[in], k[out], v[out], n, shifts[p], nbits[p], tmp, s, 0, n_pass, d0, d0 ? kept : nullptr);
+                   : radix_pass(k[in], v[in], k[out], v[out], n, shifts[p], nbits[p], tmp, s, 0, n_pass, d0, d0 ? kept : nullptr);
     }
     uint32_t kept_host = 0;
     if (drop) {

@@ -241,11 +241,8 @@ int radix_sort_pass(int pass, int npass, const uint32_t* keys_in, const uint32_t
                     uint32_t* vals_out, int64_t n, int shift, int bits, void* tmp, hipStream_t stream, int debug,
                     const uint32_t* n_dev = nullptr, bool drop = false, uint32_t* kept_out = nullptr, int items = 0,
                     int spin_limit = -1);
-// One stable LSD pass on bits [shift, shift+bits) of keys_in (bits <= 8) in TWO launches: per-workgroup histogram table (+ coarse
-// sums over groups of 32 workgroups), scatter (builds its own prefix from them; round 3 had a row-scan launch in between).
-// radix_legacy_begin(n, npass, tmp) zeroes the coarse tables of the sort's npass <= 4 passes; `pass` picks this pass' table.
-int radix_legacy_begin(int64_t n, int npass, void* tmp, hipStream_t stream);
-int radix_pass(int pass, const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
+// One stable LSD pass on bits [shift, shift+bits) of keys_in (bits <= 8): histogram table, row scan, scatter.
+int radix_pass(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
                int64_t n, int shift, int bits, void* tmp, hipStream_t stream, int debug,
                const uint32_t* n_dev = nullptr, bool drop = false, uint32_t* kept_out = nullptr);
 

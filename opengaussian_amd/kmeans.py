@@ -120,15 +120,36 @@ class Quantize_kMeans():
         self.cls_ids = torch.empty(0)               # [N] coarse id
         self.leaf_cls_ids = torch.empty(0)          # [N] fine id (k1*k2 = "unassigned")
         self.nn_index = torch.empty(0)              # [N]
-        # bookkeeping of equalize_cluster_size (consumed only by update_centers, which is a no-op on state)
-        self.cluster_ids = torch.empty(0)
-        self.excl_clusters = []
-        self.excl_cluster_ids = []
-        self.cluster_len = torch.empty(0)
-        self.max_cnt = 0
+        # bookkeeping of equalize_cluster_size (consumed only by update_centers, which is a no-op on state): built lazily,
+        # see equalize_cluster_size; the public names are properties below
+        self._table_mode = None
+        self._cluster_ids = torch.empty(0)
+        self._excl_clusters = []
+        self._excl_cluster_ids = []
+        self._cluster_len = torch.empty(0)
+        self._max_cnt = 0
         self.max_cnt_th = 10000
-        self.n_excl_cls = 0
+        self._n_excl_cls = 0
         self.pos_centers = torch.empty(0)
+
+    def _lazy(name):                                   # noqa: N805 -- class-body helper, not a method
+        priv = "_" + name
+
+        def get(self):
+            self._build_table()
+            return getattr(self, priv)
+
+        def set_(self, value):
+            self._build_table()                        # a pending rebuild must not overwrite what the caller assigns
+            setattr(self, priv, value)
+        return property(get, set_)
+    cluster_ids = _lazy("cluster_ids")
+    excl_clusters = _lazy("excl_clusters")
+    excl_cluster_ids = _lazy("excl_cluster_ids")
+    cluster_len = _lazy("cluster_len")
+    max_cnt = _lazy("max_cnt")
+    n_excl_cls = _lazy("n_excl_cls")
+    del _lazy
 
     # ---- reference helpers kept for API parity ----------------------------------------------------------
     def get_dist(self, x, y, mode='sq_euclidean'):
@@ -141,8 +162,25 @@ class Quantize_kMeans():
         return None
 
     def equalize_cluster_size(self, mode="root"):
-        """Padded per-cluster index table + lengths (kmeans_quantize.py:89-144), built with one stable sort
-        instead of a Python loop over clusters."""
+        """Padded per-cluster index table + lengths (kmeans_quantize.py:89-144).
+
+        What the training loop reads after an assign is ``cls_ids`` / ``leaf_cls_ids`` (set here, at once).  The table itself --
+        ``cluster_ids, cluster_len, max_cnt, excl_clusters, excl_cluster_ids, n_excl_cls`` -- is consumed only by
+        ``update_centers``, which is a no-op on state in the reference (:58-78), and by nothing in train.py / render(); rebuilding
+        it over ALL N points on every leaf assign (the reference does) was 90 % of a leaf assign here (bench.py `kmeans.leaf`:
+        2.0 ms of 2.2).  So the table is built LAZILY, on the first read of any of those attributes, from the ``nn_index`` of the
+        most recent call -- the same values a reader of the eager version would see."""
+        if mode == "root":
+            self.cls_ids = self.nn_index
+        elif mode == "leaf":
+            self.leaf_cls_ids = self.nn_index
+        self._table_mode = mode
+
+    def _build_table(self):
+        """The eager body of equalize_cluster_size, with one stable sort instead of the reference's Python loop over clusters."""
+        mode, self._table_mode = self._table_mode, None
+        if mode is None:
+            return
         nn = self.nn_index
         dev = nn.device
         num_clusters = self.num_clusters if mode == "root" else self.num_clusters * self.leaf_num_clusters + 1
@@ -152,11 +190,11 @@ class Quantize_kMeans():
         unq, n_unq = torch.unique(nn, return_counts=True)
         top_cnt, top_idx = torch.topk(n_unq, min(100, n_unq.numel()))        # descending; same tie order as the reference
         n_excl = int((top_cnt > self.max_cnt_th).sum())
-        self.excl_clusters = sorted(unq[top_idx[:n_excl]])
-        self.excl_cluster_ids = []
-        self.n_excl_cls = n_excl
-        self.max_cnt = top_cnt[min(n_excl, top_cnt.numel() - 1)]
-        max_cnt = int(self.max_cnt)
+        self._excl_clusters = sorted(unq[top_idx[:n_excl]])
+        self._excl_cluster_ids = []
+        self._n_excl_cls = n_excl
+        self._max_cnt = top_cnt[min(n_excl, top_cnt.numel() - 1)]
+        max_cnt = int(self._max_cnt)
         counts = torch.bincount(nn, minlength=num_clusters)[:num_clusters]
         order = torch.argsort(nn, stable=True)
         sorted_ids = nn[order]
@@ -165,15 +203,11 @@ class Quantize_kMeans():
         table = torch.full((num_clusters * max_cnt,), -1, dtype=torch.long, device=dev)
         keep = rank < max_cnt
         table[sorted_ids[keep] * max_cnt + rank[keep]] = order[keep]
-        for c in self.excl_clusters:
+        for c in self._excl_clusters:
             sel = (sorted_ids == c) & ~keep
-            self.excl_cluster_ids.append(order[sel])
-        self.cluster_ids = table
-        self.cluster_len = counts.to(torch.long).unsqueeze(1)
-        if mode == "root":
-            self.cls_ids = self.nn_index
-        elif mode == "leaf":
-            self.leaf_cls_ids = self.nn_index
+            self._excl_cluster_ids.append(order[sel])
+        self._cluster_ids = table
+        self._cluster_len = counts.to(torch.long).unsqueeze(1)
 
     # ---- the hot path -----------------------------------------------------------------------------------------
     def cluster_assign(self, feat, feat_scaled=None, mode="root", selected_leaf=-1):

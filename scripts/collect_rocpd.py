@@ -6,9 +6,10 @@ profiles/:
                                            HBM bytes per launch = 2 * FETCH_SIZE (gfx950 reports half of wide streaming
                                            reads) + WRITE_SIZE   [KiB -> bytes]
     <tag>_sq_counters_per_launch.json      SQ_* passes: per-launch averages of every counter
-    pmc_traffic.json, sq_valu.json         what bench.py attaches to its JSON line (tagged with ogs_version)
+    pmc_traffic.json, sq_valu.json         what bench.py attaches to its JSON line (tagged with ogs_version); for a workload other
+                                           than the headline: pmc_traffic_<workload>.json (the `extras` lines)
 
-usage: python scripts/collect_rocpd.py <prof_dir> <tag> <ogs_version> "<bench command>" """
+usage: python scripts/collect_rocpd.py <prof_dir> <tag> <ogs_version> "<bench command>" [workload] """
 import collections
 import csv
 import glob
@@ -92,6 +93,8 @@ def counters(dirs):
 
 def main():
     d, tag, ver, cmd = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    wl = sys.argv[5] if len(sys.argv) > 5 else "S1M-1080p"
+    headline = wl == "S1M-1080p"
     os.makedirs("profiles", exist_ok=True)
     rows = kernel_stats(os.path.join(d, "trace"), f"profiles/{tag}_kernel_stats.csv")
     fetch = counters([os.path.join(d, "fetch")])
@@ -112,11 +115,17 @@ def main():
         traffic[k] = b
         how[k] = table[k]["fetch_correction"] + " -- " + pattern
     json.dump(table, open(f"profiles/{tag}_pmc_fetch_write_per_launch.json", "w"), indent=1)
-    src = f"scripts/profile_round.sh {tag}: rocprofv3 --pmc passes of '{cmd}' (S1M-1080p fused pass, 8 views cycled)"
+    src = f"scripts/profile_round.sh {tag}: rocprofv3 --pmc passes of '{cmd}' ({wl} fused pass, 8 views cycled)"
     traffic["_ogs_version"] = ver
     traffic["_source"] = src + "; bytes = 2*FETCH_SIZE + WRITE_SIZE (KiB -> B), per launch"
     traffic["_correction_per_kernel"] = how
-    json.dump(traffic, open("profiles/pmc_traffic.json", "w"), indent=1)
+    json.dump(traffic, open("profiles/pmc_traffic.json" if headline else f"profiles/pmc_traffic_{wl}.json", "w"), indent=1)
+    if not headline:
+        print("kernel stats (top 6):")
+        for r in rows[:6]:
+            print("  %-60s calls %4d avg %9.1f us  HBM MB/launch %.1f" % ((short(r[0]) or r[0][:60]), r[1], r[3],
+                                                                         traffic.get(short(r[0]) or "", 0) / 1e6))
+        return
     sq = counters([os.path.join(d, "sq1"), os.path.join(d, "sq2")])
     for k, cs in sq.items():
         if "SQ_INSTS_VALU" in cs and "SQ_WAVES" in cs and cs["SQ_WAVES"]:
