@@ -200,29 +200,12 @@ __device__ __forceinline__ uint32_t bf16_mid_word(float x) {
     return __float_as_uint(r) + 0x8000u;
 }
 
-// MERGE (round 4, the default): the memory-side fp64 atomics are what bounds this kernel (sensitivity probes, DESIGN.md section 4:
-// +8 vector instructions per entry, one workgroup less per CU, the exact-fp32 product: no change; every atomic issued twice:
-// 0.62 -> 1.12 ms; none: 0.47 ms).  So a record no longer leaves the WAVE (one 128-byte record per (entry, quadrant): 5.4 M per
-// launch) but the TILE: the flush leaves the entry's sixteen sums -- moments shifted to the TILE centre, fp32, exact power-of-two
-// constants -- in the wave's own copy of a small table in LDS, row = the entry's compact index inside the current WINDOW of
-// kMergeW records; when all four waves have walked the window, the workgroup sums the four copies in wave order, shifts the
-// moments to the image origin in fp64 and issues ONE atomic record per (entry, tile).  A record sits at most once in a quadrant
-// stream, so a wave writes a table cell at most once per window: plain stores, nothing to race with.
-constexpr int kMergeW = 32;
-struct MergeLds {
-    float tab[kBlock / kWave][kMergeW][16];       // per wave: window row x record slot (8 KB)
-    int top[kBlock / kWave];
-};
-
-template <int C, bool DEPTH, bool BF16, bool MERGE>
+template <int C, bool DEPTH, bool BF16>
 struct PairFold {
     float* t;
-    uint32_t gidv;      // lane e: Gaussian id of staged entry e (MERGE: its compact record index in the tile)
+    uint32_t gidv;      // lane e: Gaussian id of staged entry e
     uint32_t Bw[16];    // BF16: [0..7] hi plane, [8..15] mid plane (two bf16 per dword); fp32: the sixteen B operands
-    double cA, cB, cC;  // !MERGE, this lane's slot: record value = own + cA m0 + cB mu + cC mv   (zeros on the feature slots)
-    float tA, tB, tC;   // MERGE: the same shift, quadrant centre -> tile centre (+-4, +-8, 16: exact in fp32)
-    float* tabw;        // MERGE: this wave's table copy
-    int window_lo;      // MERGE: compact index of the window's first row (wave-uniform)
+    double cA, cB, cC;  // this lane's slot: record value = own + cA m0 + cB mu + cC mv   (zeros on the feature slots)
     int cnt;            // wave-uniform: entries staged
     bool skip_atomics = false;   // timing experiment (-DOGS_EXPERIMENTS only)
 
@@ -239,15 +222,6 @@ struct PairFold {
              : n == kSlotMoments + 4 ? x0 * y0 : n == kSlotMoments + 5 ? y0 * y0 : 0.0;
         cB = n == kSlotMoments + 3 ? 2.0 * x0 : n == kSlotMoments + 4 ? y0 : 0.0;
         cC = n == kSlotMoments + 4 ? x0 : n == kSlotMoments + 5 ? 2.0 * y0 : 0.0;
-        {
-            const float xq = (wave & 1) ? 4.f : -4.f, yq = (wave >> 1) ? 4.f : -4.f;       // quadrant centre - tile centre
-            tA = n == kSlotMoments + 1 ? xq : n == kSlotMoments + 2 ? yq : n == kSlotMoments + 3 ? xq * xq
-                 : n == kSlotMoments + 4 ? xq * yq : n == kSlotMoments + 5 ? yq * yq : 0.f;
-            tB = n == kSlotMoments + 3 ? 2.f * xq : n == kSlotMoments + 4 ? yq : 0.f;
-            tC = n == kSlotMoments + 4 ? xq : n == kSlotMoments + 5 ? 2.f * yq : 0.f;
-        }
-        tabw = nullptr;
-        window_lo = 0;
         auto bval = [&](int q) {                                            // B[pixel q of the quadrant][column n]
             const int px = qx0 + (q & 7), py = qy0 + (q >> 3);
             const float u = (float)(q & 7) - 3.5f, v = (float)(q >> 3) - 3.5f;
@@ -320,16 +294,6 @@ struct PairFold {
             const float own = d[2 + rr];
             const float m0 = row_bcast<kSlotMoments>(own), mu = row_bcast<kSlotMoments + 1>(own),
                         mv = row_bcast<kSlotMoments + 2>(own);
-            if constexpr (MERGE) {
-                // g = the entry's compact index: its row of the window; tile-centred sums, fp32 (every constant a power of two
-                // or a sum of two: the products are exact)
-                float v32 = m < kSlotMoments ? d[rr] : own;
-                v32 = fmaf(tA, m0, v32);
-                v32 = fmaf(tB, mu, v32);
-                v32 = fmaf(tC, mv, v32);
-                if (e < cnt && column_used) tabw[((int)g - window_lo) * 16 + m] = v32;
-                continue;
-            }
             double val = (double)(m < kSlotMoments ? d[rr] : own);          // feature / depth slots: the w row, constants zero
             val = fma(cA, (double)m0, val);
             val = fma(cB, (double)mu, val);
@@ -382,7 +346,7 @@ __device__ __forceinline__ int wave_max_i32(int v) {
 // features): a runtime value turned every per-channel update into v_cndmask selects and kept dead math alive.
 // DEPTH = false: no gradient arrives through the depth image (dL_ddepth == NULL -- every loss of the reference,
 // gaussian_renderer/__init__.py:362 "not used"): the depth recursion and its dL/dalpha term are compiled out.
-template <int C, int GC, bool DEPTH, bool BF16, bool MERGE>
+template <int C, int GC, bool DEPTH, bool BF16>
 __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     const uint2* __restrict__ ranges, const float* __restrict__ stream, const uint32_t* __restrict__ quad_list, int W,
     int H, int gx, int tiles, const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
@@ -391,7 +355,6 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     constexpr int RS = stream_vec4(C) * 4;
     static_assert(C + 7 <= 16 && grad_stride(C) == 16, "gradient record must fit 16 slots");
     __shared__ PairFoldLds s_fold[kBlock / kWave];
-    __shared__ MergeLds s_merge;          // (MERGE only; dead otherwise)
 
     const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;                // virtual tile (grouped pass): image * tiles + tile in the image
     const int img = tile / tiles, timg = tile - img * tiles;
@@ -409,9 +372,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     const uint2 range = ranges[tile];
     const int last_contrib = inside ? (int)n_contrib[pix] : 0;
     const int hi = __builtin_amdgcn_readfirstlane(wave_max_i32(last_contrib));
-    if constexpr (!MERGE) {
-        if (hi == 0) return;                             // wave-uniform; this variant has no workgroup barriers
-    }
+    if (hi == 0) return;                                 // wave-uniform; no barriers in this kernel
     // this wave's quadrant stream (blend_fwd.hip::pack_sorted_kernel); n_contrib indexes into it
     const int n_tile = (int)(range.y - range.x);
     const float* __restrict__ tb = stream + (size_t)range.x * RS;                                    // tile's records
@@ -419,18 +380,6 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     const int n_kept = (int)qcount[tile * 5 + 4];                                                     // compacted records of the tile
     const uint32_t lim = n_kept > 0 ? (uint32_t)n_kept - 1u : 0u;
     auto rec_at = [&](uint32_t i) { return tb + (size_t)(min(i, lim) * (uint32_t)RS); };
-    // MERGE: the windows run back to front over the tile's compact record indices, from the window that holds the highest
-    // index any of the four waves will walk (the streams are ascending in the compact index: a wave's highest sits at hi - 1).
-    // A wave with nothing to walk (hi == 0) still takes part in every window's two barriers.
-    int window_lo = 0;
-    if constexpr (MERGE) {
-        for (int e = tid; e < (kBlock / kWave) * kMergeW * 16; e += kBlock) (&s_merge.tab[0][0][0])[e] = 0.f;
-        if (lane == 0) s_merge.top[wave] = hi > 0 ? (int)min(qi[hi - 1], lim) : -1;
-        __syncthreads();
-        const int top = max(max(s_merge.top[0], s_merge.top[1]), max(s_merge.top[2], s_merge.top[3]));
-        if (top < 0) return;                             // block-uniform: no pixel of the tile has a contributor
-        window_lo = (top / kMergeW) * kMergeW;
-    }
     RecordPrefetch pf;
     pf.issue(tb, n_kept, RS, tid, pf_lines & 0xFF);
 
@@ -446,48 +395,12 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     const float gd = (DEPTH && inside) ? dL_ddepth[pix] : 0.f;
     const float ga = (inside && dL_dalpha_map) ? dL_dalpha_map[pix] : 0.f;
     // every slot of the gradient record is reduced over the quadrant's pixels on the matrix cores (PairFold)
-    PairFold<C, DEPTH, BF16, MERGE> fold;
+    PairFold<C, DEPTH, BF16> fold;
     fold.skip_atomics = (pf_lines & 0x300) != 0;
     const float* __restrict__ ddepth_img = DEPTH ? dL_ddepth + (size_t)img * plane : nullptr;
     fold.init(&s_fold[wave], lane, tx, ty, wave, W, H, [&](int n, size_t p) {
         return (DEPTH && n == kSlotDepth) ? ddepth_img[p] : dcol_img[(size_t)n * plane + p];
     });
-    fold.tabw = &s_merge.tab[wave][0][0];
-    fold.window_lo = window_lo;
-    // MERGE: close the current window -- this wave's open batch goes to its table copy, the workgroup meets, every thread sums
-    // one (record, slot) cell over the four copies (wave order: deterministic), shifts the moments from the tile centre to the
-    // image origin in fp64 and adds the result to the Gaussian's gradient record; the tables are cleared on the way.
-    auto window_sync = [&]() {
-        if (fold.cnt > 0) fold.flush(grad_rec, lane);
-        __syncthreads();
-        const int n = tid & 15;
-        const double xt = (double)(tx * kTile) + 7.5, yt = (double)(ty * kTile) + 7.5;             // tile centre, image pixel coordinates
-        const double gA = n == kSlotMoments + 1 ? xt : n == kSlotMoments + 2 ? yt : n == kSlotMoments + 3 ? xt * xt
-                          : n == kSlotMoments + 4 ? xt * yt : n == kSlotMoments + 5 ? yt * yt : 0.0;
-        const double gB = n == kSlotMoments + 3 ? 2.0 * xt : n == kSlotMoments + 4 ? yt : 0.0;
-        const double gC = n == kSlotMoments + 4 ? xt : n == kSlotMoments + 5 ? 2.0 * yt : 0.0;
-#pragma unroll
-        for (int pass = 0; pass < kMergeW / 16; ++pass) {
-            const int r = pass * 16 + (tid >> 4);
-            float* cell = &s_merge.tab[0][r][n];
-            constexpr int kCopy = kMergeW * 16;
-            const float v = ((cell[0] + cell[kCopy]) + cell[2 * kCopy]) + cell[3 * kCopy];
-            cell[0] = 0.f; cell[kCopy] = 0.f; cell[2 * kCopy] = 0.f; cell[3 * kCopy] = 0.f;
-            const float m0 = row_bcast<kSlotMoments>(v), mu = row_bcast<kSlotMoments + 1>(v), mv = row_bcast<kSlotMoments + 2>(v);
-            double val = (double)v;
-            val = fma(gA, (double)m0, val);
-            val = fma(gB, (double)mu, val);
-            val = fma(gC, (double)mv, val);
-            const int cidx = window_lo + r;
-            if (cidx < n_kept && val != 0.0 && !OGS_EXP_SKIP(fold.skip_atomics)) {
-                const uint32_t gid = __float_as_uint(tb[(size_t)cidx * RS + 7]);
-                atomicAdd(grad_rec + (gid * 16u + (uint32_t)n), val);
-            }
-        }
-        __syncthreads();
-        window_lo -= kMergeW;
-        fold.window_lo = window_lo;
-    };
     float R[GC];
 #pragma unroll
     for (int c = 0; c < GC; ++c) R[c] = 0.f;
@@ -496,11 +409,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
 
     // Same SALU-frugal loop shape as blend_fwd.hip: no break / continue, two ping-pong records (no register
     // rotation), unconditional prefetch (the stream is padded in front).
-    auto consume = [&](const StreamRec<C>& rec_j, int idx, uint32_t cidx) {
-        if constexpr (MERGE) {
-            // this entry belongs to an earlier window: close the windows in between first (every wave runs the same number)
-            while ((int)cidx < window_lo) window_sync();
-        }
+    auto consume = [&](const StreamRec<C>& rec_j, int idx) {
         const f8 cur = rec_j.g;
         // blend_power(a2, b2, c2, dx, dy) with its first two products as PACKED operations on the record's even-aligned SGPR
         // pairs (x, y) and (a2, c2): v_pk_add_f32 / v_pk_mul_f32 cost one issue slot of an SGPR-operand instruction for two
@@ -555,7 +464,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
             // differentiates through the UNCLAMPED opacity * G, A.4) times a polynomial of the pixel offset: the fold takes
             // q's pixel moments, preprocess_bwd.hip does the rest
             const float q = oGa * dL_dalpha;
-            fold.push(w, q, MERGE ? cidx : __float_as_uint(cur[7]), grad_rec, lane);
+            fold.push(w, q, __float_as_uint(cur[7]), grad_rec, lane);
         }
     };
     // back-to-front over the quadrant's index stream (see blend_fwd.hip); reads below index 0 land in the previous
@@ -563,7 +472,6 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
     const uint32_t* __restrict__ q = qi + (hi - 1);
     // the loop only touches the geometry and the first GC features of a record: 12 dwords for GC <= 3 without depth
     constexpr bool kBatched = GC <= 3 && !DEPTH;
-    if (hi > 0) {
     if constexpr (kBatched) {
         // batches of two records with pinned scalar waits, as the forward walks (blend_fwd.hip): SMEM returns out of
         // order, so the only wait there is is lgkmcnt(0) = "everything in flight" -- placed BEFORE the next batch is
@@ -571,23 +479,21 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
         // right after issuing its next load, i.e. for that load too: SQ counters showed 36 % of this kernel's
         // wave-cycles parked on s_waitcnt.)  Four record register sets = 48 SGPRs here.
         StreamRec<C> a0, a1, b0, b1;
-        uint32_t i0 = min(q[0], lim), i1 = min(q[-1], lim);
-        uint32_t i2 = min(q[-2], lim), i3 = min(q[-3], lim), i4 = min(q[-4], lim), i5 = min(q[-5], lim);
-        a0.load(rec_at(i0));
-        a1.load(rec_at(i1));
+        uint32_t i2 = q[-2], i3 = q[-3], i4 = q[-4], i5 = q[-5];
+        a0.load(rec_at(q[0]));
+        a1.load(rec_at(q[-1]));
         for (int idx = hi - 1; idx >= 0; idx -= 4) {
             wait_scalar_loads();
             b0.load(rec_at(i2));
             b1.load(rec_at(i3));
-            const uint32_t n6 = min(q[-6], lim), n7 = min(q[-7], lim), n8 = min(q[-8], lim), n9 = min(q[-9], lim);
-            consume(a0, idx, i0);
-            if (idx >= 1) consume(a1, idx - 1, i1);
+            const uint32_t n6 = q[-6], n7 = q[-7], n8 = q[-8], n9 = q[-9];
+            consume(a0, idx);
+            if (idx >= 1) consume(a1, idx - 1);
             wait_scalar_loads();
             a0.load(rec_at(i4));
             a1.load(rec_at(i5));
-            if (idx >= 2) consume(b0, idx - 2, i2);
-            if (idx >= 3) consume(b1, idx - 3, i3);
-            i0 = i4; i1 = i5;
+            if (idx >= 2) consume(b0, idx - 2);
+            if (idx >= 3) consume(b1, idx - 3);
             i2 = n6; i3 = n7; i4 = n8; i5 = n9;
             q -= 4;
         }
@@ -595,26 +501,19 @@ __global__ __launch_bounds__(kBlock) void blend_backward_kernel(
         // two ping-pong records, their indices fetched one iteration ahead (wider records: four sets would not fit
         // the scalar register file)
         StreamRec<C> recA, recB;
-        uint32_t i0 = min(q[0], lim), i1 = min(q[-1], lim), i2 = min(q[-2], lim);
-        recA.load(rec_at(i0));
+        uint32_t i1 = q[-1], i2 = q[-2];
+        recA.load(rec_at(q[0]));
         for (int idx = hi - 1; idx >= 0; idx -= 2) {
             recB.load(rec_at(i1));
-            const uint32_t n3 = min(q[-3], lim), n4 = min(q[-4], lim);
-            consume(recA, idx, i0);
+            const uint32_t n3 = q[-3], n4 = q[-4];
+            consume(recA, idx);
             recA.load(rec_at(i2));
-            if (idx > 0) consume(recB, idx - 1, i1);
-            i0 = i2;
+            if (idx > 0) consume(recB, idx - 1);
             i1 = n3; i2 = n4;
             q -= 2;
         }
     }
-    }
-    if constexpr (MERGE) {
-        while (window_lo >= 0) window_sync();            // the windows this wave had nothing (more) to add to
-    }
-    if constexpr (!MERGE) {
-        if (fold.cnt > 0) fold.flush(grad_rec, lane);
-    }
+    if (fold.cnt > 0) fold.flush(grad_rec, lane);
     pf.retire(reinterpret_cast<uint32_t*>(grad_rec), W);
 }
 
@@ -810,10 +709,6 @@ static bool feat_lds_enabled() {
     return v;
 }
 
-static bool fold_merge_enabled() {
-    static const bool v = [] { const char* e = getenv("OGS_BLEND_MERGE"); return !(e && atoi(e) == 0); }();
-    return v;
-}
 static bool fold_bf16_enabled() {
     static const bool v = [] { const char* e = getenv("OGS_BLEND_FOLD"); return !(e && strcmp(e, "f32") == 0); }();
     return v;
@@ -858,35 +753,14 @@ int launch_c(const OgsRasterBwdArgs& a, const ImageState& is, void* grad_rec_, h
     // the fold's product: two-term bf16 split on v_mfma_f32_16x16x32_bf16 (default) or, OGS_BLEND_FOLD=f32, exact fp32 on
     // v_mfma_f32_16x16x4_f32 (round 2 / 3; kept for the alternative-kernel parity test and A-B timing)
     const bool bf16 = fold_bf16_enabled();
-    // OGS_BLEND_MERGE=0: one atomic record per (entry, quadrant) straight from the wave, no workgroup barriers (round 2 / 3; kept
-    // for the alternative-kernel parity test and A-B timing); default: the four quadrants' records merged per tile first
-    if (!fold_merge_enabled()) {
-#define OGS_BWD_LAUNCH_Q(GCV, DEPTHV)                                                                                 \
-    OGS_LAUNCH_NAMED(chan_name<C>(kNames), (blend_backward_kernel<C, GCV, DEPTHV, true, false>), dim3(vtiles), dim3(kBlock), 0, s, \
-                     (const uint2*)is.ranges, stream, quads, a.W, a.H, gx, gx * gy, a.bg, (const float*)is.final_T,                  \
-                     (const uint32_t*)is.n_contrib, (const uint32_t*)is.qcount, a.dL_dcolor, a.dL_ddepth, a.dL_dalpha, grad_rec,  \
-                     blend_prefetch_lines(), order)
-        const bool depthq = a.dL_ddepth != nullptr;
-        if (a.geom_channels <= 0 || a.geom_channels >= C) {
-            if (depthq) OGS_BWD_LAUNCH_Q(C, true); else OGS_BWD_LAUNCH_Q(C, false);
-        } else if (a.geom_channels == 3) {
-            if (depthq) OGS_BWD_LAUNCH_Q(3, true); else OGS_BWD_LAUNCH_Q(3, false);
-        } else {
-            set_error("backward: geom_channels must be 0, 3 or C (got %d with C=%d)", a.geom_channels, C);
-            return OGS_ERR_UNSUPPORTED;
-        }
-#undef OGS_BWD_LAUNCH_Q
-        OGS_LAUNCH_CHECK(a.debug, s);
-        return OGS_OK;
-    }
 #define OGS_BWD_LAUNCH(GCV, DEPTHV)                                                                                  \
     if (bf16)                                                                                                        \
-    OGS_LAUNCH_NAMED(chan_name<C>(kNames), (blend_backward_kernel<C, GCV, DEPTHV, true, true>), dim3(vtiles), dim3(kBlock), 0, s, \
+    OGS_LAUNCH_NAMED(chan_name<C>(kNames), (blend_backward_kernel<C, GCV, DEPTHV, true>), dim3(vtiles), dim3(kBlock), 0, s, \
                      (const uint2*)is.ranges, stream, quads, a.W, a.H, gx, gx * gy, a.bg, (const float*)is.final_T,                  \
                      (const uint32_t*)is.n_contrib, (const uint32_t*)is.qcount, a.dL_dcolor, a.dL_ddepth, a.dL_dalpha, grad_rec,  \
                      blend_prefetch_lines(), order);                                                                 \
     else                                                                                                             \
-    OGS_LAUNCH_NAMED(chan_name<C>(kNames), (blend_backward_kernel<C, GCV, DEPTHV, false, true>), dim3(vtiles), dim3(kBlock), 0, s, \
+    OGS_LAUNCH_NAMED(chan_name<C>(kNames), (blend_backward_kernel<C, GCV, DEPTHV, false>), dim3(vtiles), dim3(kBlock), 0, s, \
                      (const uint2*)is.ranges, stream, quads, a.W, a.H, gx, gx * gy, a.bg, (const float*)is.final_T,                  \
                      (const uint32_t*)is.n_contrib, (const uint32_t*)is.qcount, a.dL_dcolor, a.dL_ddepth, a.dL_dalpha, grad_rec,  \
                      blend_prefetch_lines(), order)

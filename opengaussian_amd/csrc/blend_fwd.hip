@@ -551,8 +551,13 @@ struct ChunkLds {
     uint8_t s_qnew[4][kBlock];                             // per quadrant: staging slot of every entry the chunk adds to its stream
 };
 
+// Six waves per SIMD: the kernel is sensitive to occupancy (probe: 24 KB more LDS per workgroup, three workgroups per CU instead of
+// six: 0.402 -> 0.514 ms) and its 26 KB of LDS allow six workgroups per CU, but at C = 9 the register allocator settles at 92 VGPRs
+// = five waves.  Asking for six costs six spilled dwords (80 VGPRs) and gives 0.402 -> 0.390 ms (A-B-A-B on one box); C = 12
+// cannot fit and stays where it was.
 template <int C>
-__global__ __launch_bounds__(kBlock) void pack_blend_chunked_kernel(
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8)))
+void pack_blend_chunked_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const float4* __restrict__ rec,
     float4* __restrict__ stream, uint32_t* __restrict__ quad_list, uint32_t* __restrict__ qcount, int W, int H, int gx, int tiles,
     const float* __restrict__ bg, float* __restrict__ out_color, float* __restrict__ out_depth, float* __restrict__ out_alpha,
@@ -655,7 +660,7 @@ __global__ __launch_bounds__(kBlock) void pack_blend_chunked_kernel(
             if (lane >= d) inc += t;
         }
         if (lane == kWave - 1) lds.wave_tot[wave] = inc;
-        __syncthreads();                    // (1) wave totals; also: every wave has left the previous chunk's blend
+        lds_barrier();                    // (1) wave totals; also: every wave has left the previous chunk's blend
         uint64_t before = 0, total = 0;
 #pragma unroll
         for (int w = 0; w < kBlock / kWave; ++w) {
@@ -692,7 +697,7 @@ __global__ __launch_bounds__(kBlock) void pack_blend_chunked_kernel(
             }
             quad_list[(size_t)range.x * 5 + (size_t)4 * n + c_idx] = (uint32_t)i;
         }
-        __syncthreads();                    // (2) the chunk's records and stream entries are staged
+        lds_barrier();                    // (2) the chunk's records and stream entries are staged
         {
             // record write-out for the backward: one contiguous range, the whole workgroup (stores only: nothing waits for them)
             const int kept4 = (int)((uint32_t)(total >> 48) & 0xFFFu) * SV;
@@ -757,7 +762,7 @@ __global__ __launch_bounds__(kBlock) void pack_blend_chunked_kernel(
 #pragma unroll
         for (int q = 0; q < 5; ++q) running[q] += (uint32_t)(total >> (12 * q)) & 0xFFFu;
         if (lane == 0) lds.done[wave] = all_done ? 1u : 0u;
-        __syncthreads();                    // (3) the staging buffer is free again; the four votes are in
+        lds_barrier();                    // (3) the staging buffer is free again; the four votes are in
         if ((lds.done[0] & lds.done[1] & lds.done[2] & lds.done[3]) != 0u) break;       // block-uniform
     }
     if (tid == 0) {

@@ -5,13 +5,13 @@ The reference's forward fetches a tile's list 256 entries at a time and stops th
 first pixel was blended.  For every tile of a bench workload this script reports, from the n_contrib export and the tile ranges
 of a default (culled-binning) pass:
 
-    used(t) = max over the tile's pixels of n_contrib  (1-based position of the last contributor in the tile's culled list)
-    len(t)  = length of the tile's culled list
-    chunked(t) = min(len(t), ceil(used_exit(t) / 256) * 256)   what a 256-entry-chunked pack would touch, where used_exit is the
-                 list position at which the LAST pixel of the tile saturates (T < 1e-4) or the list ends -- a tile with one
-                 unsaturated pixel has to walk its whole list, whatever its other pixels do
+    used(t)   = max over the tile's pixels of n_contrib  (1-based position of the last contributor in the tile's culled list)
+    len(t)    = length of the tile's culled list
+    packed(t) = records the chunked forward really packed before its workgroup-wide exit (qcount[t][4]) -- equals the number of
+                records the tile's list keeps when the tile ran to the end of its list
 
-and the work-weighted fractions  sum used / sum len,  sum chunked / sum len.
+and the work-weighted fractions  sum used / sum len  and  sum packed(t) / sum kept-if-fully-packed(t)  (the second from two passes:
+OGS_PACK_FUSED=2 packs every list to the end).
 
 usage: python scripts/list_depth_stats.py [workload ...]      (default: S1M-1080p C3-500k-988 C4-2M-648 C2-100k-800)
 """
@@ -54,38 +54,27 @@ def stats(workload, dev):
     keys, ranges, ncontrib, raw = helpers._export_binning_of(a, ctx.num_rendered, point_list, W, H, dev)
     gx, gy = (W + 15) // 16, (H + 15) // 16
     lens = (ranges[:, 1].astype(np.int64) - ranges[:, 0].astype(np.int64))
-    # per tile: deepest last contributor, and whether every pixel of the tile saturated (final T < 1e-4 <=> the walk stopped early)
     tiles = gx * gy
     n_pix = W * H
-    final_T = image.view(torch.float32)          # ImageState layout: ranges | n_contrib | qcount | final_T | tile_order (256-B aligned)
-    off = lambda nbytes: (nbytes + 255) // 256 * 256
+    off = lambda nbytes: (nbytes + 255) // 256 * 256          # ImageState layout: ranges | n_contrib | qcount | final_T | tile_order
     o_nc = off(tiles * 8)
     o_qc = o_nc + off(n_pix * 4)
-    o_ft = o_qc + off(tiles * 5 * 4)
-    fT = image[o_ft:o_ft + n_pix * 4].view(torch.float32).view(H, W).cpu().numpy()
+    qc = image[o_qc:o_qc + tiles * 5 * 4].view(torch.int32).view(tiles, 5).cpu().numpy().astype(np.int64)
+    packed = qc[:, 4]
     pad_h, pad_w = gy * 16, gx * 16
     nc = np.zeros((pad_h, pad_w), np.int64); nc[:H, :W] = ncontrib
-    sat = np.ones((pad_h, pad_w), bool); sat[:H, :W] = fT < 1e-4       # pixels outside the image never hold a tile back
     nc_t = nc.reshape(gy, 16, gx, 16).transpose(0, 2, 1, 3).reshape(tiles, 256)
-    sat_t = sat.reshape(gy, 16, gx, 16).transpose(0, 2, 1, 3).reshape(tiles, 256)
     used = nc_t.max(axis=1)
-    all_sat = sat_t.all(axis=1)
-    # a tile exits early only when ALL its pixels are saturated; the exit position is then a little past the deepest
-    # contributor (the entry that saturates a pixel is not applied): used + 1 is a lower bound, used itself is reported
-    exit_pos = np.where(all_sat, np.minimum(used + 1, lens), lens)
-    chunked = np.minimum(lens, (exit_pos + 255) // 256 * 256)
     nz = lens > 0
     frac = used[nz] / lens[nz]
     out = {
         "workload": workload, "tiles": int(tiles), "tiles_nonempty": int(nz.sum()),
         "num_rendered_full": int(ctx.num_rendered), "culled_list_entries": int(lens.sum()),
         "mean_culled_list": float(lens[nz].mean()), "max_culled_list": int(lens.max()),
-        "tiles_fully_saturated_frac": float(all_sat[nz].mean()),
+        "records_packed_before_the_exit": int(packed.sum()),
         "used_over_len": {"median": float(np.median(frac)), "mean": float(frac.mean()),
                           "p10": float(np.percentile(frac, 10)), "p90": float(np.percentile(frac, 90))},
-        "work_weighted": {"sum_used_over_sum_len": float(used[nz].sum() / lens[nz].sum()),
-                          "sum_exit_over_sum_len": float(exit_pos[nz].sum() / lens[nz].sum()),
-                          "sum_chunked256_over_sum_len": float(chunked[nz].sum() / lens[nz].sum())},
+        "work_weighted": {"sum_used_over_sum_len": float(used[nz].sum() / lens[nz].sum())},
     }
     return out
 
@@ -94,6 +83,10 @@ def main():
     dev = torch.device("cuda:0")
     names = sys.argv[1:] or ["S1M-1080p", "C3-500k-988", "C4-2M-648", "C2-100k-800"]
     res = [stats(n, dev) for n in names]
+    mode = os.environ.get("OGS_PACK_FUSED", "1")
+    for r in res:
+        r["pack_mode"] = {"1": "chunked with workgroup-wide exit (default)", "2": "whole list packed (round 3)",
+                          "0": "two launches, whole list packed"}.get(mode, mode)
     print(json.dumps(res, indent=1))
 
 
