@@ -685,7 +685,7 @@ int radix_pass(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_
     if (items == 4) {
         OGS_LAUNCH(radix_hist_kernel<4>, dim3(nb), dim3(kBlock), 0, stream, keys_in, n, n_dev, shift, bits, hist, nb, drop);
     } else {
-        OGS_LAUNCH(radix_hist_kernel<16>, dim3(nb), dim3(kBlock), 0, stream, keys_in, n, n_dev, shift, bits, hist, nb, drop);
+        OGS_LAUNCH(radix_hist_kernel<8>, dim3(nb), dim3(kBlock), 0, stream, keys_in, n, n_dev, shift, bits, hist, nb, drop);
     }
     OGS_LAUNCH_CHECK(debug, stream);
     OGS_LAUNCH(radix_rowscan_kernel, dim3(ndig), dim3(kBlock), 0, stream, hist, nb, row_total);
@@ -694,7 +694,7 @@ int radix_pass(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_
         OGS_LAUNCH(radix_scatter_kernel<4>, dim3(nb), dim3(kBlock), 0, stream, keys_in, vals_in, keys_out, vals_out, n, n_dev,
                    shift, bits, (const uint32_t*)hist, (const uint32_t*)row_total, nb, drop, kept_out);
     } else {
-        OGS_LAUNCH(radix_scatter_kernel<16>, dim3(nb), dim3(kBlock), 0, stream, keys_in, vals_in, keys_out, vals_out, n, n_dev,
+        OGS_LAUNCH(radix_scatter_kernel<8>, dim3(nb), dim3(kBlock), 0, stream, keys_in, vals_in, keys_out, vals_out, n, n_dev,
                    shift, bits, (const uint32_t*)hist, (const uint32_t*)row_total, nb, drop, kept_out);
     }
     OGS_LAUNCH_CHECK(debug, stream);

@@ -588,7 +588,9 @@ void pack_blend_chunked_kernel(
     for (int k = 0; k < NPF; ++k) accp[k] = (v2f){0.f, 0.f};
     float wacc = 0.f;
     uint32_t last = 0;
-    bool all_done = __ballot(inside) == 0ull;               // a quadrant outside the image has nothing to wait for
+    // pixels still blending, as a wave-uniform 64-bit mask (an SGPR pair: a `bool all_done` went through a VGPR and back on every
+    // walk step); a quadrant outside the image starts with none
+    uint64_t alive = __ballot(inside);
 
     const float4* __restrict__ recs = lds.s_rec;
     uint32_t* __restrict__ mylist = lds.s_list[wave][row];
@@ -618,7 +620,7 @@ void pack_blend_chunked_kernel(
             T = stop ? T : test_T;
             last = w > 0.f ? jplus1 : last;
             fxe = stop ? kFar : fxe;
-            if (__ballot(stop) != 0ull) all_done = __ballot(fxe < kFarTest) == 0ull;
+            if (__ballot(stop) != 0ull) alive = __ballot(fxe < kFarTest);
         }
     };
 
@@ -707,7 +709,7 @@ void pack_blend_chunked_kernel(
         // ================= blend what the chunk added to this wave's quadrant stream =================
         const int cnt_q = (int)((uint32_t)(total >> (12 * wave)) & 0xFFFu);
         const uint32_t j0 = wave == 0 ? running[0] : wave == 1 ? running[1] : wave == 2 ? running[2] : running[3];
-        for (int c0 = 0; c0 < cnt_q && !all_done; c0 += kWave) {
+        for (int c0 = 0; c0 < cnt_q && alive != 0ull; c0 += kWave) {
             const int cnt = min(kWave, cnt_q - c0);
             const bool have = lane < cnt;
             const uint32_t cl = have ? (uint32_t)lds.s_qnew[wave][c0 + lane] : (uint32_t)kBlock;
@@ -749,7 +751,7 @@ void pack_blend_chunked_kernel(
             uint32_t e0 = mylist[0], e1 = mylist[1];
             ra.load_lds(rec_of(e0));
             const uint32_t jbase = j0 + (uint32_t)c0 + 1u;
-            for (int t = 0; t < maxlen && !all_done; t += 2) {
+            for (int t = 0; t < maxlen && alive != 0ull; t += 2) {
                 const uint32_t e2 = mylist[t + 2], e3 = mylist[t + 3];
                 rb.load_lds(rec_of(e1));
                 consume(ra, jbase + (e0 >> 16));
@@ -761,7 +763,7 @@ void pack_blend_chunked_kernel(
         }
 #pragma unroll
         for (int q = 0; q < 5; ++q) running[q] += (uint32_t)(total >> (12 * q)) & 0xFFFu;
-        if (lane == 0) lds.done[wave] = all_done ? 1u : 0u;
+        if (lane == 0) lds.done[wave] = alive == 0ull ? 1u : 0u;
         lds_barrier();                    // (3) the staging buffer is free again; the four votes are in
         if ((lds.done[0] & lds.done[1] & lds.done[2] & lds.done[3]) != 0u) break;       // block-uniform
     }

@@ -65,6 +65,13 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
     float gr[kSlotMoments];
 #pragma unroll
     for (int k = 0; k < kSlotMoments; ++k) gr[k] = (float)g64[k];
+    // A visible Gaussian that received NO gradient -- every slot of its record still zero: hidden behind saturated pixels, which
+    // is four Gaussians out of five on a ScanNet-class view where the tiles stop at 15 % of their lists (section 3b) -- owes
+    // zeros everywhere: its inputs (192 B of SH coefficients, scale, rotation, mean) are not read and nothing is evaluated.
+    // (Round 4; at C4-class this kernel is the largest of the step: P = 2 M behind a 648 x 484 image.)
+    bool touched = false;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) touched = touched || g64[k] != 0.0;
     // Slots 10..15: moments of q = opacity * G * dL/dalpha over the Gaussian's pixels (X, Y) about the IMAGE ORIGIN (the blend
     // kernel's waves only know their quadrant; blend_bwd.hip::PairFold).  Re-centred here on the pixel centre the blend used,
     // d = centre - pixel, in fp64 -- |X|^2 / sigma^2 can reach ~1e7, far inside the 1e16 of the format:
@@ -75,7 +82,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
     //   dL/dconic  = -1/2 sum q * (dx^2, dx dy, dy^2)          dL/dopacity = sum G dL/dalpha = S0 / opacity
     const float d_depth = gr[kSlotDepth];
     float dm2x = 0.f, dm2y = 0.f, dconA = 0.f, dconB = 0.f, dconC = 0.f, dopac = 0.f;
-    if (vis && !feat_only_layout) {
+    if (vis && touched && !feat_only_layout) {
         const float4 ge = rec[(size_t)idx * rec_vec4(C)];              // pixel centre (px, py), depth, radius
         const float4 co = rec[(size_t)idx * rec_vec4(C) + 1];          // conic A, B, C, opacity: what the blend used
         const double cx = (double)ge.x, cy = (double)ge.y;
@@ -114,7 +121,7 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
 
     const bool need_geom = dL_dmeans3D || dL_dcov3D || dL_dscales || dL_drotations || dL_dsh || dL_dsh_rgb;
     float drgb_out[3] = {0.f, 0.f, 0.f};
-    if (vis && need_geom) {
+    if (vis && touched && need_geom) {
         float V[16], M[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) { V[i] = viewmatrix[i]; M[i] = projmatrix[i]; }

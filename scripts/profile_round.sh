@@ -23,3 +23,7 @@ if [ "$WL" = "S1M-1080p" ]; then
 fi
 VER=$(python3 -c "from opengaussian_amd import _lib; print(int(_lib.lib().ogs_version()))")
 python3 scripts/collect_rocpd.py $OUT $TAG $VER "$BENCH" $WL
+# the raw rocpd databases are tens of MB per pass: gpurun merges at most 64 MiB of gpurun_out/ back -- keep the logs and the
+# summaries (a copy of what went to profiles/) only
+rm -rf $OUT/trace $OUT/fetch $OUT/write $OUT/sq1 $OUT/sq2
+mkdir -p gpurun_out/profiles_out && cp profiles/${TAG}_* profiles/pmc_traffic*.json profiles/sq_valu.json gpurun_out/profiles_out/ 2>/dev/null || true
