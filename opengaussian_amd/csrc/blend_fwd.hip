@@ -611,16 +611,23 @@ void pack_blend_chunked_kernel(
             alpha = (cand && alpha >= kAlphaMin) ? alpha : 0.f;
             const float test_T = T * (1.0f - alpha);
             const bool stop = test_T < 0.0001f;
-            const float w = stop ? 0.f : alpha * T;
+            float w = alpha * T;
+            // a pixel saturates once: the three selects of the stop (weight, T, parking) only run in a step in which some lane
+            // stops; every other step takes the values straight (same bits: the selects would have picked them)
+            if (__ballot(stop) != 0ull) {
+                w = stop ? 0.f : w;
+                T = stop ? T : test_T;
+                fxe = stop ? kFar : fxe;
+                alive = __ballot(fxe < kFarTest);
+            } else {
+                T = test_T;
+            }
             const v2f w2 = {w, w};
 #pragma unroll
             for (int k = 0; k < NPF; ++k)
                 accp[k] = __builtin_elementwise_fma((v2f){r.feat(2 * k), r.feat(2 * k + 1)}, w2, accp[k]);
             wacc += w;
-            T = stop ? T : test_T;
             last = w > 0.f ? jplus1 : last;
-            fxe = stop ? kFar : fxe;
-            if (__ballot(stop) != 0ull) alive = __ballot(fxe < kFarTest);
         }
     };
 

@@ -398,7 +398,9 @@ def test_bench_stage1_switch_two_ranks(gpu_device):
     assert out["n_gpus"] == 2 and out["value"] > 0 and "STAGE-1" in out["config"]["workload"]
     d = out["dist"]
     assert d["exchange_bytes_per_step_per_rank"] == 100_000 * 24
-    assert "blend_backward_feat" in out["roofline"]["kernel"] or "pack_blend" in out["roofline"]["kernel"], out["roofline"]
+    # (which kernel dominates is not asserted: two ranks share the one GPU of the test box, and an event pair around a launch
+    # then brackets the other rank's kernels as well)
+    assert out["roofline"] is not None and out["roofline"]["algorithmic_bytes_per_launch"] > 0, out["roofline"]
     assert d["stage0_all_gradient_step"]["ms_per_step"] > 0
 
 
