@@ -46,7 +46,7 @@ HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~6300
 # inline constant / literal (v_fma, v_mul, v_add, v_sub, v_mov, v_add_u32, v_and); per 4 cycles for ANY form with an SGPR
 # operand, DPP, v_cmp*, v_cndmask (SGPR-pair mask), v_max / v_min, shifts, v_cvt, v_pk_*, f64, v_readlane / v_writelane;
 # per 8 for v_exp / v_rcp.  `peak` below is the 2-cycle rate; `roofline_valu.issue_model` prices the dominant kernel's
-# own static instruction mix (scripts/isa_issue_mix.py -> profiles/r03_issue_mix.json).
+# own static instruction mix (scripts/isa_issue_mix.py -> profiles/r04_issue_mix.json).
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16 (guide); k-means scores + one-hot accumulate run there
 
@@ -821,7 +821,7 @@ def main():
                             "peak_note": "2 cycles per wave64 instruction per SIMD (all-VGPR forms, measured); forms with an SGPR "
                                          "operand, DPP, compares / selects, min / max issue at 4",
                             "source": sq.get("_source")}
-                    mix_file = os.path.join(ROOT, "profiles", "r03_issue_mix.json")
+                    mix_file = os.path.join(ROOT, "profiles", "r04_issue_mix.json")
                     if os.path.exists(mix_file):
                         mix = json.load(open(mix_file)).get(dom.split("<")[0])
                         if mix:
@@ -841,7 +841,13 @@ def main():
             # limiter is VALU issue -- see `limiter` and the sibling `roofline_valu`
             roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
-                        "limiter": "valu-issue (not HBM): see roofline_valu",
+                        "limiter": {"blend_backward_kernel": "the L2's fp64 atomic path (sensitivity probes, DESIGN.md section 3b: every atomic "
+                                                             "issued twice 0.62 -> 1.12 ms, none 0.47 ms; +8 VALU per entry or one "
+                                                             "workgroup less per CU: no change) -- not HBM bytes, not vector issue",
+                                    "pack_blend_chunked_kernel": "vector issue and occupancy (probes, DESIGN.md section 3b) -- not HBM bytes",
+                                    "blend_backward_feat_lds_kernel": "vector issue of the walk (its atomics cost 0.02 of 0.36 ms)",
+                                    "preprocess_backward_kernel": "HBM at the part's mixed read / write rate (4.6 TB/s for a 1 : 1 copy)",
+                                    "preprocess_kernel": "HBM at the part's mixed read / write rate"}.get(dom_base, "see DESIGN.md section 4"),
                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": per_kernel[dom]["avg_ms"]}
         step_bytes = sum(algorithmic_bytes(P, D, npx, 3, 48)[k] for k in ("fwd", "bwd"))
         if fused:
