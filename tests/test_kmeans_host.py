@@ -63,3 +63,25 @@ def test_cpu_features_are_refused():
     q = Quantize_kMeans(num_clusters=4, num_leaf_clusters=2, num_iters=1)
     with pytest.raises(RuntimeError, match="no CPU path"):
         q.forward(G(), 1, assign=True, mode="root")
+
+
+def test_index_table_is_built_lazily_and_matches_the_eager_result():
+    """Round 4: equalize_cluster_size sets cls_ids / leaf_cls_ids at once but builds its padded index table (kmeans_quantize.py:
+    89-144; read by nothing in the training loop) on the first access of cluster_ids / cluster_len / max_cnt / excl_* -- from the
+    nn_index of the most recent call, so a reader sees exactly what the eager version held."""
+    g = torch.Generator().manual_seed(5)
+    q = Quantize_kMeans(num_clusters=8, num_leaf_clusters=3)
+    q.nn_index = torch.randint(0, 8, (2000,), generator=g)
+    q.equalize_cluster_size(mode="root")
+    assert q.cls_ids is q.nn_index and q._table_mode == "root"           # ids at once, table still pending
+    first = q.nn_index
+    q.nn_index = torch.randint(0, 8, (2000,), generator=g)                 # a second assign before anyone looked
+    q.equalize_cluster_size(mode="root")
+    lens = q.cluster_len                                                   # first access builds it, from the LATEST ids
+    assert q._table_mode is None
+    assert torch.equal(lens.reshape(-1), torch.bincount(q.nn_index, minlength=8))
+    assert not torch.equal(lens.reshape(-1), torch.bincount(first, minlength=8))
+    ids, _, _ = _loop_restatement(q.nn_index, 8, int(q.max_cnt), [int(c) for c in q.excl_clusters])
+    assert torch.equal(q.cluster_ids, ids)
+    q.cluster_ids = torch.zeros(3, dtype=torch.long)                       # attributes stay plain assignable
+    assert q.cluster_ids.shape == (3,)
