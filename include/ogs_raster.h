@@ -223,7 +223,26 @@ int ogs_raster_forward_render_deferred(const OgsRasterFwdArgs* args, int64_t cap
 size_t ogs_raster_tiny_max_points(void);
 int ogs_raster_forward_tiny(const OgsRasterFwdArgs* args, void* stream);
 
-/* Backward.  Asynchronous on `stream`. */
+/* Re-blend of a KEPT pass (new capability; no reference counterpart -- the reference re-runs preprocess, both sorts and the
+ * duplication on every call).  From stage 1 on the reference trains `_ins_feat` alone (train.py:431-436: every other Gaussian
+ * parameter is detached) and renders without the random footprint rescale (train.py:346-350: rescale only in stage 2), so for a
+ * given camera every later pass rebuilds, entry for entry, the binning state of the first one; only the feature channels of the
+ * blended records differ.  A caller that kept image_buffer, sorted_rec and quad_list of a finished ungrouped pass (and its
+ * radii) renders again with TWO launches: channels [F0, C) of every packed record are rewritten from `colors_precomp`, then the
+ * kept quadrant streams are blended -- images, depth, alpha, n_contrib and final_T bit for bit what a full pass over the same
+ * inputs returns.  F0 = 3 and colors_precomp = [P, C-3] when the kept pass was a fused SH pass (flagged by sh_coeffs != 0: its
+ * channels 0..2, the SH colours of the frozen coefficients for this camera, stay), else F0 = 0 and colors_precomp = [P, C].
+ * Read: P, W, H, C, sh_coeffs, debug, bg, colors_precomp, out_color / out_depth / out_alpha, image_buffer, sorted_rec, quad_list;
+ * everything else is ignored.  The caller owns the validity of the kept state: same means / scales / rotations / opacities / SH
+ * coefficients, camera, image size, scale_modifier and binning mode as the kept pass (opengaussian_amd/rasterizer.py keys it on
+ * the parameters' storage and version counters).  A features-only ogs_raster_backward on the kept state follows as after any
+ * forward.  Asynchronous. */
+int ogs_raster_forward_reblend(const OgsRasterFwdArgs* args, void* stream);
+
+/* Backward.  Asynchronous on `stream`.  In the features-only case (see OgsRasterBwdArgs) only P, W, H, C, num_rendered,
+ * num_groups, radii, dL_dcolor, image_buffer, sorted_rec, quad_list, bwd_tmp, dL_dcolors are read, `colors_precomp` and `shs`
+ * are only tested against NULL (shs != NULL: fused SH pass, dL_dcolors is [P, C-3]); the other inputs, geom_buffer and
+ * point_list may be NULL. */
 int ogs_raster_backward(const OgsRasterBwdArgs* args, void* stream);
 
 /* Replaces upstream mark_visible(means3D, viewmatrix, projmatrix) -> bool[P]: near-plane test

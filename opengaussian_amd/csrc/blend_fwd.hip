@@ -1112,6 +1112,73 @@ int launch_c(const OgsRasterFwdArgs& a, const GeomState& gs, const ImageState& i
     return OGS_OK;
 }
 
+// ---- re-blend of a kept pass (frozen geometry, round 4) ----------------------------------------------------------------
+// From stage 1 on the reference trains `_ins_feat` alone (train.py:431-436): for a given camera every later pass bins, sorts and
+// packs exactly what the first one did, only the feature channels of the records differ.  A caller that kept image_buffer,
+// sorted_rec and quad_list of such a pass (rasterizer.py: the frozen-geometry cache) re-renders with TWO launches: this kernel
+// rewrites channels [F0, C) of every packed record from the current per-Gaussian features (the record knows its Gaussian: slot
+// 7), then the stand-alone forward blend walks the kept quadrant streams.  Eight lanes per record: one lane per channel, the
+// 24 / 36 bytes of a record's channels and of a Gaussian's row are contiguous.
+template <int C, int F0>
+__global__ __launch_bounds__(kBlock) void refresh_features_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ qcount,
+                                                                  float* __restrict__ stream, const float* __restrict__ feats,
+                                                                  const uint32_t* __restrict__ tile_order) {
+    constexpr int RS = stream_vec4(C) * 4;
+    constexpr int E = C - F0;                  // channels rewritten
+    constexpr int LPR = E <= 8 ? 8 : 16;       // lanes per record
+    const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
+    const uint2 range = ranges[tile];
+    const int n_kept = (int)qcount[tile * 5 + 4];
+    float* __restrict__ tb = stream + (size_t)range.x * RS;
+    const int k = (int)threadIdx.x & (LPR - 1);
+    for (int i = (int)threadIdx.x / LPR; i < n_kept; i += kBlock / LPR) {
+        float* r = tb + (size_t)i * RS;
+        const uint32_t g = __float_as_uint(r[7]);
+        if (k < E) r[8 + F0 + k] = feats[(size_t)g * E + k];
+    }
+}
+
+template <int C>
+int reblend_c(const OgsRasterFwdArgs& a, const ImageState& is, hipStream_t s) {
+    const int gx = (a.W + kTile - 1) / kTile, gy = (a.H + kTile - 1) / kTile;
+    const int tiles = gx * gy;
+    const unsigned vtiles = (unsigned)tiles;
+    const uint32_t* order = tile_order_of(is, vtiles, a.P);        // written by the kept pass
+    static constexpr const char* const kRefresh[4] = {"refresh_features_kernel<3>", "refresh_features_kernel<6>",
+                                                      "refresh_features_kernel<9>", "refresh_features_kernel<12>"};
+    float* stream = reinterpret_cast<float*>(stream_base<C>(a.sorted_rec));
+    if (a.sh_coeffs != 0) {
+        if constexpr (C > 3) {
+            OGS_LAUNCH_NAMED(chan_name<C>(kRefresh), (refresh_features_kernel<C, 3>), dim3(vtiles), dim3(kBlock), 0, s,
+                             (const uint2*)is.ranges, (const uint32_t*)is.qcount, stream, a.colors_precomp, order);
+        } else {
+            set_error("forward_reblend: a 3-channel SH pass has no channel to rewrite");
+            return OGS_ERR_INVALID_ARG;
+        }
+    } else {
+        OGS_LAUNCH_NAMED(chan_name<C>(kRefresh), (refresh_features_kernel<C, 0>), dim3(vtiles), dim3(kBlock), 0, s,
+                         (const uint2*)is.ranges, (const uint32_t*)is.qcount, stream, a.colors_precomp, order);
+    }
+    OGS_LAUNCH_CHECK(a.debug, s);
+    if (blend_rows_enabled()) {
+        static constexpr const char* const kRows[4] = {"blend_forward_rows_kernel<3>", "blend_forward_rows_kernel<6>",
+                                                       "blend_forward_rows_kernel<9>", "blend_forward_rows_kernel<12>"};
+        OGS_LAUNCH_NAMED(chan_name<C>(kRows), blend_forward_rows_kernel<C>, dim3(vtiles), dim3(kBlock), 0, s,
+                         (const uint2*)is.ranges, (const uint32_t*)is.qcount, (const float*)stream,
+                         (const uint32_t*)quad_base(a.quad_list), a.W, a.H, gx, tiles, a.bg, a.out_color, a.out_depth,
+                         a.out_alpha, is.n_contrib, is.final_T, blend_prefetch_lines(), order);
+    } else {
+        static constexpr const char* const kNames[4] = {"blend_forward_kernel<3>", "blend_forward_kernel<6>",
+                                                        "blend_forward_kernel<9>", "blend_forward_kernel<12>"};
+        OGS_LAUNCH_NAMED(chan_name<C>(kNames), blend_forward_kernel<C>, dim3(vtiles), dim3(kBlock), 0, s,
+                         (const uint2*)is.ranges, (const uint32_t*)is.qcount, (const float*)stream,
+                         (const uint32_t*)quad_base(a.quad_list), a.W, a.H, gx, tiles, a.bg, a.out_color, a.out_depth,
+                         a.out_alpha, is.n_contrib, is.final_T, blend_prefetch_lines(), order);
+    }
+    OGS_LAUNCH_CHECK(a.debug, s);
+    return OGS_OK;
+}
+
 template <int C>
 int export_c(const OgsRasterFwdArgs& a, const ImageState& is, uint32_t* out, hipStream_t s) {
     const int gx = (a.W + kTile - 1) / kTile, gy = (a.H + kTile - 1) / kTile;
@@ -1153,6 +1220,16 @@ int launch_blend_forward(const OgsRasterFwdArgs& a, const GeomState& gs, const I
         case 6: return launch_c<6>(a, gs, is, D, s);
         case 9: return launch_c<9>(a, gs, is, D, s);
         case 12: return launch_c<12>(a, gs, is, D, s);
+        default: set_error("unsupported channel count C=%d", a.C); return OGS_ERR_UNSUPPORTED;
+    }
+}
+
+int launch_reblend(const OgsRasterFwdArgs& a, const ImageState& is, hipStream_t s) {
+    switch (a.C) {
+        case 3: return reblend_c<3>(a, is, s);
+        case 6: return reblend_c<6>(a, is, s);
+        case 9: return reblend_c<9>(a, is, s);
+        case 12: return reblend_c<12>(a, is, s);
         default: set_error("unsupported channel count C=%d", a.C); return OGS_ERR_UNSUPPORTED;
     }
 }

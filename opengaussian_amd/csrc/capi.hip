@@ -349,6 +349,23 @@ int ogs_raster_forward_render_deferred(const OgsRasterFwdArgs* a, int64_t capaci
     return render_impl(a, capacity, true, static_cast<hipStream_t>(stream_));
 }
 
+// Re-blend of a kept pass (include/ogs_raster.h): same geometry, same lists, new feature channels.
+int ogs_raster_forward_reblend(const OgsRasterFwdArgs* a, void* stream_) {
+    if (!a) { set_error("args == NULL"); return OGS_ERR_INVALID_ARG; }
+    if (a->P <= 0 || a->W <= 0 || a->H <= 0) { set_error("forward_reblend: bad sizes P=%d W=%d H=%d", a->P, a->W, a->H); return OGS_ERR_INVALID_ARG; }
+    if (a->C != 3 && a->C != 6 && a->C != 9 && a->C != 12) { set_error("C=%d unsupported (3, 6, 9, 12)", a->C); return OGS_ERR_UNSUPPORTED; }
+    if (a->num_groups > 1) { set_error("forward_reblend: grouped passes are not kept"); return OGS_ERR_UNSUPPORTED; }
+    if (!a->colors_precomp || !a->bg || !a->out_color || !a->out_depth || !a->out_alpha || !a->image_buffer || !a->sorted_rec ||
+        !a->quad_list) {
+        set_error("forward_reblend: NULL required pointer (colors_precomp, bg, out_*, image_buffer, sorted_rec, quad_list)");
+        return OGS_ERR_INVALID_ARG;
+    }
+    const int rc = check_async_status("forward_reblend (entry)");
+    if (rc != OGS_OK) return rc;
+    const ImageState is = ImageState::carve(a->image_buffer, a->W, a->H, 1);
+    return launch_reblend(*a, is, static_cast<hipStream_t>(stream_));
+}
+
 size_t ogs_raster_tiny_max_points(void) { return (size_t)kTinyMaxP; }
 
 int ogs_raster_forward_tiny(const OgsRasterFwdArgs* a, void* stream_) {
@@ -368,11 +385,16 @@ int ogs_raster_backward(const OgsRasterBwdArgs* a, void* stream_) {
     if (!a) { set_error("args == NULL"); return OGS_ERR_INVALID_ARG; }
     if (a->C != 3 && a->C != 6 && a->C != 9) { set_error("backward: C=%d unsupported (3, 6, 9)", a->C); return OGS_ERR_UNSUPPORTED; }
     if (a->P == 0) return OGS_OK;
-    if (!a->dL_dcolor || !a->geom_buffer || !a->image_buffer || !a->bwd_tmp || !a->radii || !a->bg ||
-        !a->means3D || !a->viewmatrix || !a->projmatrix || !a->campos) {
+    // the features-only pass reads the blend state and the radii alone: a caller that kept only those (the re-blend of a kept
+    // pass, ogs_raster_forward_reblend) may leave the per-Gaussian inputs, geom_buffer and point_list NULL
+    const bool feat_only = backward_is_features_only(*a);
+    if (!a->dL_dcolor || !a->image_buffer || !a->bwd_tmp || !a->radii) {
         set_error("backward: NULL required pointer"); return OGS_ERR_INVALID_ARG;
     }
-    if (a->num_rendered > 0 && !a->point_list) { set_error("backward: point_list == NULL"); return OGS_ERR_INVALID_ARG; }
+    if (!feat_only && (!a->geom_buffer || !a->bg || !a->means3D || !a->viewmatrix || !a->projmatrix || !a->campos)) {
+        set_error("backward: NULL required pointer"); return OGS_ERR_INVALID_ARG;
+    }
+    if (!feat_only && a->num_rendered > 0 && !a->point_list) { set_error("backward: point_list == NULL"); return OGS_ERR_INVALID_ARG; }
     // the blend kernels address the gradient record with 32-bit element offsets (g * 16 + slot, SGPR-base atomics)
     if ((int64_t)a->P * grad_stride(a->C) >= (1ll << 32)) {
         set_error("backward: P=%d exceeds the %lld Gaussians the 32-bit gradient-record offsets address", a->P,

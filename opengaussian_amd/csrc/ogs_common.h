@@ -307,6 +307,8 @@ int launch_preprocess(const OgsRasterFwdArgs& a, const GeomState& gs, const Geom
 int launch_tiny_geometry(const OgsRasterFwdArgs& a, const GeomState& gs, uint32_t* order, hipStream_t s);
 int launch_small_geometry(const OgsRasterFwdArgs& a, const GeomState& gs, const GeomTmp& gt, hipStream_t s);
 int launch_tiny_blend(const OgsRasterFwdArgs& a, const GeomState& gs, const uint32_t* order, hipStream_t s);
+// re-blend of a kept pass with new feature channels (blend_fwd.hip::refresh_features_kernel + the stand-alone forward blend)
+int launch_reblend(const OgsRasterFwdArgs& a, const ImageState& is, hipStream_t s);
 // zero_ranges / n_zero (optional, n_zero <= P): the kernel also clears that many tile ranges (then launch_tile_ranges is told so)
 int launch_duplicate(const OgsRasterFwdArgs& a, const GeomState& gs, const GeomTmp& gt, uint32_t* tile_keys,
                      uint32_t* vals, uint32_t capacity, bool drop_unreachable, hipStream_t s, uint2* zero_ranges = nullptr,

@@ -42,7 +42,7 @@ _HINT_WINDOW = 32
 # how the render phase of every forward was sized: "blocking" (first pass at a size, grouped / debug passes: the
 # reference's 4-byte read-back), "deferred" (sync-free, capacity from the hint), "overflow" (deferred result
 # discarded, render phase redone with exact buffers)
-PASS_STATS = {"blocking": 0, "deferred": 0, "overflow": 0, "tiny": 0, "tiny_rerendered_for_backward": 0}
+PASS_STATS = {"blocking": 0, "deferred": 0, "overflow": 0, "tiny": 0, "tiny_rerendered_for_backward": 0, "reblend": 0}
 
 
 def _hint_capacity(key):
@@ -259,7 +259,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                 raster_settings: GaussianRasterizationSettings, geom_channels: int = 0, sh_rgb_sink=None,
-                group_ids=None, num_groups: int = 1):
+                group_ids=None, num_groups: int = 1, keep_sink=None):
         rs = raster_settings
         ctx.geom_channels = int(geom_channels)
         ctx.sh_rgb_sink = sh_rgb_sink
@@ -348,6 +348,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(m3, shs, cols, opac, scl, rot, cov, bg, view, proj, campos, radii, alpha, geom, image,
                               point_list, sorted_rec, quad_list)
         ctx.mark_non_differentiable(radii)
+        if keep_sink is not None and G == 1 and D > 0:
+            # frozen-geometry cache (KeptPasses below): what a re-blend of this pass needs
+            keep_sink.append({"P": P, "W": W, "H": H, "Cn": Cn, "fused": shs is not None and cols is not None, "D": D,
+                              "image": image, "sorted_rec": sorted_rec, "quad_list": quad_list, "radii": radii,
+                              "full_binning": bool(FULL_BINNING)})
         return color, radii, depth, alpha
 
     @staticmethod
@@ -355,7 +360,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         P, Cn = ctx.P, ctx.Cn
         if P == 0:
-            return (None,) * 13
+            return (None,) * 14
         lib = _lib.lib()
         H, W = int(rs.image_height), int(rs.image_width)
         scratch = None
@@ -424,7 +429,170 @@ class _RasterizeGaussians(torch.autograd.Function):
             _DEBUG_KEEP_BWD_TMP.append(bwd_tmp)
         if sink is not None:
             sink.append(g_sh_rgb)
-        return g_m3, g_m2, g_sh, g_col, g_op, g_scl, g_rot, g_cov, None, None, None, None, None
+        return g_m3, g_m2, g_sh, g_col, g_op, g_scl, g_rot, g_cov, None, None, None, None, None, None
+
+
+# ---- kept passes: the frozen-geometry cache ------------------------------------------------------------------------------
+# From stage 1 on the reference trains `_ins_feat` alone: train.py:431-436 detaches every other Gaussian parameter, and the
+# stage-1 calls render without the random footprint rescale (train.py:346-350).  For a given camera every such call rebuilds,
+# entry for entry, the binning state of the previous one -- preprocess, both sorts, the duplication and pack are spent on
+# reproducing bytes that already exist.  With 288 GB of HBM they can simply stay: a finished pass whose caller vouches for its
+# geometry (`frozen_key`, renderer.py builds it from the parameters' storages and version counters) leaves image_buffer, the
+# compacted records, the quadrant streams and the radii behind (~0.35 GB for a 1080p view of 1 M Gaussians, exact size after a
+# prefix copy), and the next pass with the same key is ogs_raster_forward_reblend: rewrite the records' feature channels, blend.
+# Images, depth, alpha, radii and the feature gradients are bit for bit those of a full pass (tests/test_14_kept_pass_gpu.py).
+class _KeptPass:
+    __slots__ = ("key", "holds", "P", "W", "H", "Cn", "E", "fused", "D", "image", "sorted_rec", "quad_list", "radii", "nbytes",
+                 "hits", "full_binning")
+
+
+class KeptPasses:
+    """One kept pass per SLOT (a camera); a slot whose key changed (parameters stepped, replaced, another image size ...) is
+    dropped on lookup.  Admission stops at the byte budget -- nothing is evicted to make room: the training loop draws its
+    cameras from a shuffled stack (train.py:296-299), the access pattern on which least-recently-used eviction hits nothing
+    once the working set exceeds the budget, while a fixed resident subset keeps hitting for its share of the views."""
+
+    def __init__(self, budget_bytes=None):
+        self.budget_bytes = budget_bytes          # None: OGS_KEPT_PASSES_GB, default a quarter of the device's memory
+        self.slots: dict = {}
+        self.nbytes = 0
+        self.stats = {"hits": 0, "misses": 0, "stale": 0, "admitted": 0, "rejected_budget": 0}
+
+    def _budget(self, dev) -> int:
+        if self.budget_bytes is None:
+            env = os.environ.get("OGS_KEPT_PASSES_GB")
+            if env is not None:
+                self.budget_bytes = int(float(env) * (1 << 30))
+            else:
+                self.budget_bytes = int(torch.cuda.get_device_properties(dev).total_memory) // 4
+        return self.budget_bytes
+
+    def enabled(self, dev) -> bool:
+        return self._budget(dev) > 0
+
+    def lookup(self, slot, key):
+        e = self.slots.get(slot)
+        if e is None:
+            self.stats["misses"] += 1
+            return None
+        if e.key != key:
+            self.drop(slot)
+            self.stats["stale"] += 1
+            self.stats["misses"] += 1
+            return None
+        e.hits += 1
+        self.stats["hits"] += 1
+        return e
+
+    def drop(self, slot):
+        e = self.slots.pop(slot, None)
+        if e is not None:
+            self.nbytes -= e.nbytes
+
+    def clear(self):
+        self.slots.clear()
+        self.nbytes = 0
+
+    def admit(self, slot, key, holds, kept: dict) -> bool:
+        """kept: what _RasterizeGaussians.forward left in its keep_sink.  The record array and the quadrant streams of the pass
+        were sized for a CAPACITY (1.25 x the recent maximum of num_rendered, and the reachable pairs are about half of it):
+        the used prefix is copied into exact-size buffers -- one 4-byte read-back per admitted view."""
+        dev = kept["image"].device
+        lib = _lib.lib()
+        W, H, Cn = kept["W"], kept["H"], kept["Cn"]
+        tiles = ((W + 15) // 16) * ((H + 15) // 16)
+        ranges = kept["image"][: tiles * 8].view(torch.int32).view(tiles, 2)
+        used = int(ranges[:, 1].max().item())                # entries of the (culled) sorted list
+        if used <= 0:
+            return False
+        srb, qlb = int(lib.ogs_raster_sorted_bytes(used, Cn)), int(lib.ogs_raster_quad_list_bytes(used))
+        if srb > kept["sorted_rec"].numel() or qlb > kept["quad_list"].numel():
+            return False
+        nbytes = srb + qlb + kept["image"].numel() + kept["radii"].numel() * 4
+        if self.nbytes + nbytes > self._budget(dev):
+            self.stats["rejected_budget"] += 1
+            return False
+        e = _KeptPass()
+        e.key, e.holds = key, holds
+        e.P, e.W, e.H, e.Cn, e.fused, e.D = kept["P"], W, H, Cn, bool(kept["fused"]), used
+        e.E = Cn - 3 if e.fused else Cn
+        e.full_binning = kept["full_binning"]
+        e.image, e.radii = kept["image"], kept["radii"]
+        e.sorted_rec = kept["sorted_rec"][:srb].clone()
+        e.quad_list = kept["quad_list"][:qlb].clone()
+        e.nbytes, e.hits = nbytes, 0
+        self.drop(slot)
+        self.slots[slot] = e
+        self.nbytes += nbytes
+        self.stats["admitted"] += 1
+        return True
+
+
+KEPT_PASSES = KeptPasses()
+
+
+class _ReblendKept(torch.autograd.Function):
+    """forward: ogs_raster_forward_reblend on a kept pass; backward: the features-only ogs_raster_backward on the same state."""
+
+    @staticmethod
+    def forward(ctx, extra_feats, entry: _KeptPass, raster_settings: GaussianRasterizationSettings):
+        rs = raster_settings
+        ctx.set_materialize_grads(False)
+        _require_gpu(extra_feats, "colors_precomp")
+        dev = extra_feats.device
+        lib = _lib.lib()
+        P, W, H, Cn = entry.P, entry.W, entry.H, entry.Cn
+        cols = _f32c(extra_feats)
+        if cols is None or tuple(cols.shape) != (P, entry.E):
+            raise RuntimeError(f"the kept pass blends {entry.E} caller channels of {P} Gaussians, got {tuple(extra_feats.shape)}")
+        bg = _f32c(rs.bg.to(dev))
+        if bg is None or bg.numel() != Cn:
+            if bg is not None and bg.numel() == 3 and Cn > 3:
+                bg = _tiled_bg(bg, Cn)
+            else:
+                raise RuntimeError(f"bg must have {Cn} entries")
+        color = torch.empty(Cn, H, W, dtype=torch.float32, device=dev)
+        depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+        alpha = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+        a = OgsRasterFwdArgs()
+        a.P, a.W, a.H, a.C = P, W, H, Cn
+        a.sh_coeffs = 1 if entry.fused else 0          # flag only: channels 0..2 of the kept records stay (header)
+        a.debug = int(bool(rs.debug))
+        a.bg, a.colors_precomp = ptr(bg), ptr(cols)
+        a.out_color, a.out_depth, a.out_alpha = ptr(color), ptr(depth), ptr(alpha)
+        a.image_buffer, a.sorted_rec, a.quad_list = ptr(entry.image), ptr(entry.sorted_rec), ptr(entry.quad_list)
+        check(lib.ogs_raster_forward_reblend(C.byref(a), _stream()), "ogs_raster_forward_reblend")
+        PASS_STATS["reblend"] += 1
+        ctx.entry, ctx.raster_settings = entry, rs
+        ctx.save_for_backward(cols)
+        radii = entry.radii.detach()                   # an alias: the pass' radii are those of the kept pass
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth, alpha
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
+        if not ctx.needs_input_grad[0]:
+            return None, None, None
+        e, rs = ctx.entry, ctx.raster_settings
+        (cols,) = ctx.saved_tensors
+        dev = cols.device
+        lib = _lib.lib()
+        gc = _f32c(grad_color)
+        if gc is None:
+            return torch.zeros_like(cols), None, None
+        g_col = torch.empty(e.P, e.E, dtype=torch.float32, device=dev)
+        bwd_tmp = torch.empty(int(lib.ogs_raster_backward_tmp_bytes(e.P)), dtype=torch.uint8, device=dev)
+        b = OgsRasterBwdArgs()
+        b.P, b.W, b.H, b.C = e.P, e.W, e.H, e.Cn
+        b.debug = int(bool(rs.debug))
+        b.num_rendered, b.num_groups = int(e.D), 1
+        b.colors_precomp = ptr(cols)
+        b.shs = ptr(cols) if e.fused else None         # tested against NULL only in the features-only pass (header)
+        b.radii, b.dL_dcolor = ptr(e.radii), ptr(gc)
+        b.image_buffer, b.sorted_rec, b.quad_list, b.bwd_tmp = ptr(e.image), ptr(e.sorted_rec), ptr(e.quad_list), ptr(bwd_tmp)
+        b.dL_dcolors = ptr(g_col)
+        check(lib.ogs_raster_backward(C.byref(b), _stream()), "ogs_raster_backward")
+        return g_col, None, None
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -437,7 +605,7 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
 
 
 def rasterize_fused(means3D, means2D, opacities, shs, extra_feats, raster_settings, scales=None, rotations=None,
-                    cov3D_precomp=None, detach_extra_from_geometry=True, sh_rgb_sink=None):
+                    cov3D_precomp=None, detach_extra_from_geometry=True, sh_rgb_sink=None, frozen_key=None):
     """ONE pass for what the reference renders in several (gaussian_renderer/__init__.py:104-163): RGB from SH in
     channels 0..2 plus `extra_feats` [P, 3|6|9] (e.g. the 6-D ins_feat) in the following channels -- one
     preprocess / sort / blend for all of them.  Returns (color [3+E,H,W], radii, depth, alpha).
@@ -445,12 +613,32 @@ def rasterize_fused(means3D, means2D, opacities, shs, extra_feats, raster_settin
     detach_extra_from_geometry=True reproduces the stage-1/2 training graph (train.py:431-436): the loss on the
     extra channels reaches only `extra_feats`; geometry, opacity and means2D receive gradient from the RGB /
     depth / alpha outputs alone -- bit-for-bit what two separate reference passes (RGB with all gradients, feature
-    pass with everything else detached) would accumulate."""
+    pass with everything else detached) would accumulate.
+
+    frozen_key (extension): ``(slot, key, holds)`` -- the caller vouches that every input but `extra_feats` (and the
+    background) is the same whenever `key` is the same (renderer.py: storages + version counters of the model's parameters,
+    the camera, the image size).  When none of those inputs requires grad, the first pass of a slot is kept (KEPT_PASSES,
+    budget OGS_KEPT_PASSES_GB, 0 = off) and later passes with an equal key re-blend it: two launches instead of the
+    whole binning pipeline, same bits.  `holds` (any object) is kept alive with the entry so that the addresses in `key`
+    cannot be recycled while it exists."""
     empty = torch.Tensor([])
-    return _RasterizeGaussians.apply(means3D, means2D, shs, extra_feats, opacities,
-                                     empty if scales is None else scales, empty if rotations is None else rotations,
-                                     empty if cov3D_precomp is None else cov3D_precomp, raster_settings,
-                                     3 if detach_extra_from_geometry else 0, sh_rgb_sink)
+    args = (means3D, means2D, shs, extra_feats, opacities, empty if scales is None else scales,
+            empty if rotations is None else rotations, empty if cov3D_precomp is None else cov3D_precomp, raster_settings,
+            3 if detach_extra_from_geometry else 0, sh_rgb_sink)
+    if frozen_key is None or not means3D.is_cuda or not KEPT_PASSES.enabled(means3D.device) or raster_settings.debug or \
+            (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in
+                                             (means3D, means2D, opacities, shs, scales, rotations, cov3D_precomp))):
+        return _RasterizeGaussians.apply(*args)
+    slot, key, holds = frozen_key
+    key = (key, bool(FULL_BINNING), int(extra_feats.shape[-1]))
+    entry = KEPT_PASSES.lookup(slot, key)
+    if entry is not None:
+        return _ReblendKept.apply(extra_feats, entry, raster_settings)
+    sink: list = []
+    out = _RasterizeGaussians.apply(*args, None, 1, sink)
+    if sink:
+        KEPT_PASSES.admit(slot, key, holds, sink[0])
+    return out
 
 
 def rasterize_groups(means3D, means2D, opacities, group_ids, num_groups, raster_settings, shs=None,

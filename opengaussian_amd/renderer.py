@@ -98,6 +98,42 @@ def _render_subsets(group_of_point: torch.Tensor, num_groups: int, min_points: i
     return kept_list, imgs, sils
 
 
+_MODEL_PARAMS = ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest")
+
+
+def _frozen_geometry_key(viewpoint_camera, pc, pipe, xyz, scaling_modifier):
+    """``(slot, key, holds)`` for rasterizer.rasterize_fused(frozen_key=...) or None.
+
+    Stage >= 1 of the reference's schedule: the six geometry / appearance parameters of the model are detached
+    (train.py:431-436) and nothing steps them any more, so the binning state of a camera's pass can be kept.  What vouches for
+    "nothing changed": the storage address and torch's version counter of each parameter (every in-place update -- an optimizer
+    step, `reset_opacity`, densification's `cat` -- bumps the counter or moves the storage; `.detach()`, which train.py repeats
+    every iteration, does neither), the camera's matrices likewise, and the scalar settings of the pass.  The tensors are held
+    by the entry, so an address cannot be handed out again while its key is in use.  NOT covered: writes through `.data` or
+    raw pointers (they leave the counter alone) -- call ``rasterizer.KEPT_PASSES.clear()`` after such a write, or set
+    OGS_KEPT_PASSES_GB=0.  Returns None when the model does not look like the reference's GaussianModel (no such attributes,
+    `get_xyz` not the `_xyz` parameter itself), when anything still requires grad, or under `pipe.debug`."""
+    if getattr(pipe, "debug", False) or getattr(pipe, "compute_cov3D_python", False) or getattr(pipe, "convert_SHs_python", False):
+        return None
+    params = []
+    for name in _MODEL_PARAMS:
+        t = getattr(pc, name, None)
+        if not isinstance(t, torch.Tensor) or t.requires_grad or not t.is_cuda:
+            return None
+        params.append(t)
+    if params[0].data_ptr() != xyz.data_ptr():
+        return None
+    cam = (viewpoint_camera.world_view_transform, viewpoint_camera.full_proj_transform, viewpoint_camera.camera_center)
+    if not all(isinstance(t, torch.Tensor) for t in cam):
+        return None
+    ident = lambda t: (t.data_ptr(), t._version, tuple(t.shape))
+    key = (tuple(ident(t) for t in params), tuple(ident(t) for t in cam), int(viewpoint_camera.image_height),
+           int(viewpoint_camera.image_width), float(viewpoint_camera.FoVx), float(viewpoint_camera.FoVy),
+           float(scaling_modifier), int(pc.active_sh_degree))
+    slot = (cam[0].data_ptr(), int(viewpoint_camera.image_height), int(viewpoint_camera.image_width))
+    return slot, key, (tuple(params), cam)
+
+
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, iteration,
            scaling_modifier=1.0, override_color=None, visible_mask=None, mask_num=0,
            cluster_idx=None, leaf_cluster_idx=None, rescale=True, origin_feat=False,
@@ -178,9 +214,12 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, iteration,
     if can_fuse:
         # RGB + features + silhouette on identical geometry: one bin / sort / blend for everything
         if shs is not None:
+            # stage >= 1 (everything but ins_feat frozen, no rescale draw): the camera's first pass is kept, later ones re-blend it
+            frozen = None if (viewspace_grad or scales is None) else _frozen_geometry_key(viewpoint_camera, pc, pipe, xyz,
+                                                                                          scaling_modifier)
             out, radii, rendered_depth, rendered_alpha = rasterize_fused(
                 means3D, means2D, opacity, shs, ins_feat, raster_settings, scales=scales * rescale_factor,
-                rotations=rotations, cov3D_precomp=cov3D_precomp, detach_extra_from_geometry=False)
+                rotations=rotations, cov3D_precomp=cov3D_precomp, detach_extra_from_geometry=False, frozen_key=frozen)
         else:
             out, radii, rendered_depth, rendered_alpha = rasterizer(
                 means3D=means3D, means2D=means2D, shs=None, colors_precomp=torch.cat((colors_precomp, ins_feat), dim=1),
