@@ -325,7 +325,7 @@ def stage1_bench(leaves, all_settings, gF, P, device, reps=40):
     out = {"ms_per_step": dt * 1e3, "Mpix_per_s": W * H / dt / 1e6,
            "kernels_ms": {k: v["total_ms"] / v["calls"] for k, v in prof.items() if "backward" in k or "blend" in k}}
     # the same step with the camera's pass KEPT (rasterizer.KEPT_PASSES: frozen geometry, stage-1 calls draw no rescale,
-    # train.py:346-350): forward = rewrite the records' feature channels + blend
+    # train.py:346-350): forward = ONE blend launch over the kept streams, feature channels read from the current tensor
     try:
         from opengaussian_amd import rasterizer as R
         saved, R.KEPT_PASSES = R.KEPT_PASSES, R.KeptPasses(budget_bytes=24 << 30)

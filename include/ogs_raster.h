@@ -228,9 +228,10 @@ int ogs_raster_forward_tiny(const OgsRasterFwdArgs* args, void* stream);
  * parameter is detached) and renders without the random footprint rescale (train.py:346-350: rescale only in stage 2), so for a
  * given camera every later pass rebuilds, entry for entry, the binning state of the first one; only the feature channels of the
  * blended records differ.  A caller that kept image_buffer, sorted_rec and quad_list of a finished ungrouped pass (and its
- * radii) renders again with TWO launches: channels [F0, C) of every packed record are rewritten from `colors_precomp`, then the
- * kept quadrant streams are blended -- images, depth, alpha, n_contrib and final_T bit for bit what a full pass over the same
- * inputs returns.  F0 = 3 and colors_precomp = [P, C-3] when the kept pass was a fused SH pass (flagged by sh_coeffs != 0: its
+ * radii) renders again with ONE launch: the forward blend walks the kept quadrant streams and takes channels [F0, C) of every
+ * record from `colors_precomp` (by the Gaussian id the record carries) instead of the record -- images, depth, alpha, n_contrib
+ * and final_T bit for bit what a full pass over the same inputs returns; the kept buffers are only read (n_contrib / final_T are
+ * rewritten with the values they hold).  F0 = 3 and colors_precomp = [P, C-3] when the kept pass was a fused SH pass (flagged by sh_coeffs != 0: its
  * channels 0..2, the SH colours of the frozen coefficients for this camera, stay), else F0 = 0 and colors_precomp = [P, C].
  * Read: P, W, H, C, sh_coeffs, debug, bg, colors_precomp, out_color / out_depth / out_alpha, image_buffer, sorted_rec, quad_list;
  * everything else is ignored.  The caller owns the validity of the kept state: same means / scales / rotations / opacities / SH

@@ -333,12 +333,15 @@ struct RowsLds {
 };
 
 // one tile; n = this wave's quadrant count, n_kept = records kept by the tile (qcount[tile * 5 + wave / 4])
-template <int C>
+// RF >= 0 (re-blend of a kept pass, ogs_raster_forward_reblend): channels [RF, C) of every record come from the caller's CURRENT
+// per-Gaussian features `feats` [P, C - RF] instead of the record -- the lane that gathers a record fetches its Gaussian's row
+// (slot 7 of the record is the id) on the way into LDS; the kept records are never written.
+template <int C, int RF = -1>
 __device__ __forceinline__ void blend_rows_tile(
     const uint2 range, int n, int n_kept, const float* __restrict__ stream,
     const uint32_t* __restrict__ quad_list, int W, int H, int gx, int img, int timg, const float* __restrict__ bg, float* __restrict__ out_color,
     float* __restrict__ out_depth, float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib,
-    float* __restrict__ final_T, int pf_lines, RowsLds<C>& lds) {
+    float* __restrict__ final_T, int pf_lines, RowsLds<C>& lds, const float* __restrict__ feats = nullptr) {
     constexpr int NV4 = stream_vec4(C);
     constexpr int RS = NV4 * 4;                  // floats per stream record
     constexpr int kListLen = kRowListLen;
@@ -414,6 +417,16 @@ __device__ __forceinline__ void blend_rows_tile(
         float4 r[NV4];
 #pragma unroll
         for (int k = 0; k < NV4; ++k) r[k] = rp[k];
+        if constexpr (RF >= 0) {
+            constexpr int E = C - RF;
+            const float* __restrict__ fp = feats + (size_t)__float_as_uint(r[1].w) * E;
+            float fv[E];
+#pragma unroll
+            for (int k = 0; k < E; ++k) fv[k] = fp[k];
+            float* rf = reinterpret_cast<float*>(r);
+#pragma unroll
+            for (int k = 0; k < E; ++k) rf[8 + RF + k] = fv[k];
+        }
 #pragma unroll
         for (int k = 0; k < NV4; ++k) recs[lane * NV4 + k] = r[k];
         bool reach[4];
@@ -479,18 +492,18 @@ __device__ __forceinline__ void blend_rows_tile(
     pf.retire(n_contrib, W);
 }
 
-template <int C>
+template <int C, int RF = -1>
 __global__ __launch_bounds__(kBlock) void blend_forward_rows_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ qcount, const float* __restrict__ stream,
     const uint32_t* __restrict__ quad_list, int W, int H, int gx, int tiles, const float* __restrict__ bg, float* __restrict__ out_color,
     float* __restrict__ out_depth, float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib,
-    float* __restrict__ final_T, int pf_lines, const uint32_t* __restrict__ tile_order) {
+    float* __restrict__ final_T, int pf_lines, const uint32_t* __restrict__ tile_order, const float* __restrict__ feats) {
     __shared__ RowsLds<C> lds;
     const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
     const int img = tile / tiles, timg = tile - img * tiles;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    blend_rows_tile<C>(ranges[tile], (int)qcount[tile * 5 + wave], (int)qcount[tile * 5 + 4], stream, quad_list, W, H, gx, img, timg, bg,
-                       out_color, out_depth, out_alpha, n_contrib, final_T, pf_lines, lds);
+    blend_rows_tile<C, RF>(ranges[tile], (int)qcount[tile * 5 + wave], (int)qcount[tile * 5 + 4], stream, quad_list, W, H, gx, img, timg,
+                           bg, out_color, out_depth, out_alpha, n_contrib, final_T, pf_lines, lds, feats);
 }
 
 // ---- pack + forward blend of a tile in ONE workgroup (round 3) -------------------------------------------------------
@@ -1100,7 +1113,7 @@ int launch_c(const OgsRasterFwdArgs& a, const GeomState& gs, const ImageState& i
         OGS_LAUNCH_NAMED(chan_name<C>(kRows), blend_forward_rows_kernel<C>, dim3(vtiles), dim3(kBlock), 0, s,
                          (const uint2*)is.ranges, (const uint32_t*)is.qcount, (const float*)stream_base<C>(a.sorted_rec),
                          (const uint32_t*)quad_base(a.quad_list), a.W, a.H, gx, tiles, a.bg, a.out_color, a.out_depth,
-                         a.out_alpha, is.n_contrib, is.final_T, blend_prefetch_lines(), order);
+                         a.out_alpha, is.n_contrib, is.final_T, blend_prefetch_lines(), order, (const float*)nullptr);
         OGS_LAUNCH_CHECK(a.debug, s);
         return OGS_OK;
     }
@@ -1115,66 +1128,35 @@ int launch_c(const OgsRasterFwdArgs& a, const GeomState& gs, const ImageState& i
 // ---- re-blend of a kept pass (frozen geometry, round 4) ----------------------------------------------------------------
 // From stage 1 on the reference trains `_ins_feat` alone (train.py:431-436): for a given camera every later pass bins, sorts and
 // packs exactly what the first one did, only the feature channels of the records differ.  A caller that kept image_buffer,
-// sorted_rec and quad_list of such a pass (rasterizer.py: the frozen-geometry cache) re-renders with TWO launches: this kernel
-// rewrites channels [F0, C) of every packed record from the current per-Gaussian features (the record knows its Gaussian: slot
-// 7), then the stand-alone forward blend walks the kept quadrant streams.  Eight lanes per record: one lane per channel, the
-// 24 / 36 bytes of a record's channels and of a Gaussian's row are contiguous.
-template <int C, int F0>
-__global__ __launch_bounds__(kBlock) void refresh_features_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ qcount,
-                                                                  float* __restrict__ stream, const float* __restrict__ feats,
-                                                                  const uint32_t* __restrict__ tile_order) {
-    constexpr int RS = stream_vec4(C) * 4;
-    constexpr int E = C - F0;                  // channels rewritten
-    constexpr int LPR = E <= 8 ? 8 : 16;       // lanes per record
-    const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
-    const uint2 range = ranges[tile];
-    const int n_kept = (int)qcount[tile * 5 + 4];
-    float* __restrict__ tb = stream + (size_t)range.x * RS;
-    const int k = (int)threadIdx.x & (LPR - 1);
-    for (int i = (int)threadIdx.x / LPR; i < n_kept; i += kBlock / LPR) {
-        float* r = tb + (size_t)i * RS;
-        const uint32_t g = __float_as_uint(r[7]);
-        if (k < E) r[8 + F0 + k] = feats[(size_t)g * E + k];
-    }
-}
-
+// sorted_rec and quad_list of such a pass (rasterizer.py: KeptPasses) re-renders with ONE launch: the stand-alone forward blend
+// walks the kept quadrant streams and takes channels [F0, C) of every record from the current per-Gaussian features
+// (blend_rows_tile<C, RF>).  (First version: a kernel that rewrote the channels inside the kept records, then the plain blend --
+// 0.13 ms at the bench scene for the read-modify-write of 24 bytes in every 80-byte record, against 0.32 ms for the blend.)
 template <int C>
 int reblend_c(const OgsRasterFwdArgs& a, const ImageState& is, hipStream_t s) {
     const int gx = (a.W + kTile - 1) / kTile, gy = (a.H + kTile - 1) / kTile;
     const int tiles = gx * gy;
     const unsigned vtiles = (unsigned)tiles;
     const uint32_t* order = tile_order_of(is, vtiles, a.P);        // written by the kept pass
-    static constexpr const char* const kRefresh[4] = {"refresh_features_kernel<3>", "refresh_features_kernel<6>",
-                                                      "refresh_features_kernel<9>", "refresh_features_kernel<12>"};
-    float* stream = reinterpret_cast<float*>(stream_base<C>(a.sorted_rec));
+    static constexpr const char* const kRows[4] = {"blend_forward_rows_kernel<3, refresh>", "blend_forward_rows_kernel<6, refresh>",
+                                                   "blend_forward_rows_kernel<9, refresh>", "blend_forward_rows_kernel<12, refresh>"};
+    const float* stream = reinterpret_cast<const float*>(stream_base<C>(a.sorted_rec));
+#define OGS_REBLEND(RFV)                                                                                                    \
+    OGS_LAUNCH_NAMED(chan_name<C>(kRows), (blend_forward_rows_kernel<C, RFV>), dim3(vtiles), dim3(kBlock), 0, s,           \
+                     (const uint2*)is.ranges, (const uint32_t*)is.qcount, stream, (const uint32_t*)quad_base(a.quad_list), a.W,  \
+                     a.H, gx, tiles, a.bg, a.out_color, a.out_depth, a.out_alpha, is.n_contrib, is.final_T,                  \
+                     blend_prefetch_lines(), order, a.colors_precomp)
     if (a.sh_coeffs != 0) {
         if constexpr (C > 3) {
-            OGS_LAUNCH_NAMED(chan_name<C>(kRefresh), (refresh_features_kernel<C, 3>), dim3(vtiles), dim3(kBlock), 0, s,
-                             (const uint2*)is.ranges, (const uint32_t*)is.qcount, stream, a.colors_precomp, order);
+            OGS_REBLEND(3);
         } else {
-            set_error("forward_reblend: a 3-channel SH pass has no channel to rewrite");
+            set_error("forward_reblend: a 3-channel SH pass has no channel to replace");
             return OGS_ERR_INVALID_ARG;
         }
     } else {
-        OGS_LAUNCH_NAMED(chan_name<C>(kRefresh), (refresh_features_kernel<C, 0>), dim3(vtiles), dim3(kBlock), 0, s,
-                         (const uint2*)is.ranges, (const uint32_t*)is.qcount, stream, a.colors_precomp, order);
+        OGS_REBLEND(0);
     }
-    OGS_LAUNCH_CHECK(a.debug, s);
-    if (blend_rows_enabled()) {
-        static constexpr const char* const kRows[4] = {"blend_forward_rows_kernel<3>", "blend_forward_rows_kernel<6>",
-                                                       "blend_forward_rows_kernel<9>", "blend_forward_rows_kernel<12>"};
-        OGS_LAUNCH_NAMED(chan_name<C>(kRows), blend_forward_rows_kernel<C>, dim3(vtiles), dim3(kBlock), 0, s,
-                         (const uint2*)is.ranges, (const uint32_t*)is.qcount, (const float*)stream,
-                         (const uint32_t*)quad_base(a.quad_list), a.W, a.H, gx, tiles, a.bg, a.out_color, a.out_depth,
-                         a.out_alpha, is.n_contrib, is.final_T, blend_prefetch_lines(), order);
-    } else {
-        static constexpr const char* const kNames[4] = {"blend_forward_kernel<3>", "blend_forward_kernel<6>",
-                                                        "blend_forward_kernel<9>", "blend_forward_kernel<12>"};
-        OGS_LAUNCH_NAMED(chan_name<C>(kNames), blend_forward_kernel<C>, dim3(vtiles), dim3(kBlock), 0, s,
-                         (const uint2*)is.ranges, (const uint32_t*)is.qcount, (const float*)stream,
-                         (const uint32_t*)quad_base(a.quad_list), a.W, a.H, gx, tiles, a.bg, a.out_color, a.out_depth,
-                         a.out_alpha, is.n_contrib, is.final_T, blend_prefetch_lines(), order);
-    }
+#undef OGS_REBLEND
     OGS_LAUNCH_CHECK(a.debug, s);
     return OGS_OK;
 }

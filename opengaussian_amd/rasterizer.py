@@ -439,7 +439,8 @@ class _RasterizeGaussians(torch.autograd.Function):
 # reproducing bytes that already exist.  With 288 GB of HBM they can simply stay: a finished pass whose caller vouches for its
 # geometry (`frozen_key`, renderer.py builds it from the parameters' storages and version counters) leaves image_buffer, the
 # compacted records, the quadrant streams and the radii behind (~0.35 GB for a 1080p view of 1 M Gaussians, exact size after a
-# prefix copy), and the next pass with the same key is ogs_raster_forward_reblend: rewrite the records' feature channels, blend.
+# prefix copy), and the next pass with the same key is ogs_raster_forward_reblend: ONE launch, the forward blend over the kept
+# streams with the records' feature channels taken from the caller's current tensor (the kept records are never written).
 # Images, depth, alpha, radii and the feature gradients are bit for bit those of a full pass (tests/test_14_kept_pass_gpu.py).
 class _KeptPass:
     __slots__ = ("key", "holds", "P", "W", "H", "Cn", "E", "fused", "D", "image", "sorted_rec", "quad_list", "radii", "nbytes",
@@ -618,7 +619,7 @@ def rasterize_fused(means3D, means2D, opacities, shs, extra_feats, raster_settin
     frozen_key (extension): ``(slot, key, holds)`` -- the caller vouches that every input but `extra_feats` (and the
     background) is the same whenever `key` is the same (renderer.py: storages + version counters of the model's parameters,
     the camera, the image size).  When none of those inputs requires grad, the first pass of a slot is kept (KEPT_PASSES,
-    budget OGS_KEPT_PASSES_GB, 0 = off) and later passes with an equal key re-blend it: two launches instead of the
+    budget OGS_KEPT_PASSES_GB, 0 = off) and later passes with an equal key re-blend it: one launch instead of the
     whole binning pipeline, same bits.  `holds` (any object) is kept alive with the entry so that the addresses in `key`
     cannot be recycled while it exists."""
     empty = torch.Tensor([])

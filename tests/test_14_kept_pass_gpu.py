@@ -1,7 +1,7 @@
 """GPU: the frozen-geometry cache (rasterizer.KEPT_PASSES, ogs_raster_forward_reblend).
 
 From stage 1 on the reference trains `_ins_feat` alone (train.py:431-436) and renders the stage-1 views without the random
-footprint rescale (train.py:346-350): a camera's pass is kept, later passes rewrite the records' feature channels and blend.
+footprint rescale (train.py:346-350): a camera's pass is kept, later passes blend the kept streams with the current feature channels.
 The contract under test: a re-blend returns, BIT FOR BIT, what a full pass over the same inputs returns (images, depth, alpha,
 radii), its feature gradient is the full pass' features-only gradient, and a key that changed never hits."""
 import types
