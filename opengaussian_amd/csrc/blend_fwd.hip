@@ -381,17 +381,23 @@ __device__ __forceinline__ void blend_rows_tile(
     uint32_t last = 0;
     bool all_done = false;
 
-    auto consume = [&](const RowRec<C>& rec, uint32_t jplus1) {
-        const float dx = rec.at(0) - fxe, dy = rec.at(1) - fy;
-        const float power = blend_power(rec.at(2), rec.at(4), rec.at(3), dx, dy);
+    constexpr uint32_t kNoEntry = 0xFFFFFFFFu;
+    uint32_t last_e = kNoEntry;          // list entry (slot << 16 | LDS offset) of the pixel's last contributor in the current chunk
+    auto consume = [&](const RowRec<C>& rec, uint32_t entry) {
+        // blend_power() with packed subtractions / first products (see pack_blend_chunked_kernel): same bits
+        const v2f d = (v2f){rec.at(0), rec.at(1)} - (v2f){fxe, fy};
+        const v2f m = (v2f){rec.at(2), rec.at(3)} * d;
+        const float u = fmaf(rec.at(4), d.y, m.x);
+        const float power = fmaf(m.y, d.y, u * d.x);
         const float h = rec.at(5);
         const bool cand = fabsf(power + h) <= h;
         if (__ballot(cand) != 0ull) {
             // straight-line for all 64 lanes (no exec-mask region: a lane that is no candidate gets alpha = 0, which leaves
             // every one of its accumulators, its T and its `last` untouched -- w = 0, test_T = T >= 1e-4 -- so the values of
             // the contributing lanes are the same operations on the same operands as before)
-            float alpha = fminf(0.99f, rec.at(6) * __expf(power));
-            alpha = (cand && alpha >= kAlphaMin) ? alpha : 0.f;
+            const float araw = fminf(0.99f, rec.at(6) * __expf(power));
+            const bool act = cand && araw >= kAlphaMin;
+            const float alpha = act ? araw : 0.f;
             const float test_T = T * (1.0f - alpha);
             const bool stop = test_T < 0.0001f;
             const float w = stop ? 0.f : alpha * T;
@@ -401,7 +407,7 @@ __device__ __forceinline__ void blend_rows_tile(
                 accp[k] = __builtin_elementwise_fma((v2f){rec.feat(2 * k), rec.feat(2 * k + 1)}, w2, accp[k]);
             wacc += w;
             T = stop ? T : test_T;
-            last = w > 0.f ? jplus1 : last;
+            last_e = (act && !stop) ? entry : last_e;      // w > 0 <=> act && !stop; see pack_blend_chunked_kernel
             fxe = stop ? kFar : fxe;
             if (__ballot(stop) != 0ull) all_done = __ballot(fxe < kFarTest) == 0ull;
         }
@@ -470,11 +476,13 @@ __device__ __forceinline__ void blend_rows_tile(
         for (int t = 0; t < maxlen && !all_done; t += 2) {
             const uint32_t e2 = mylist[t + 2], e3 = mylist[t + 3];
             rb.load_lds(rec_of(e1));
-            consume(ra, (uint32_t)c0 + (e0 >> 16) + 1u);
+            consume(ra, e0);
             ra.load_lds(rec_of(e2));
-            if (t + 1 < maxlen) consume(rb, (uint32_t)c0 + (e1 >> 16) + 1u);
+            if (t + 1 < maxlen) consume(rb, e1);
             e0 = e2; e1 = e3;
         }
+        if (last_e != kNoEntry) last = (uint32_t)c0 + (last_e >> 16) + 1u;      // list entry -> 1-based stream index
+        last_e = kNoEntry;
         __builtin_amdgcn_wave_barrier();
     }
 
@@ -614,17 +622,30 @@ void pack_blend_chunked_kernel(
         lds.s_rec[kBlock * SV + 1] = float4{0.f, -1.f, 0.f, 0.f};
     }
 
-    auto consume = [&](const RowRec<C>& r, uint32_t jplus1) {
-        const float dx = r.at(0) - fxe, dy = r.at(1) - fy;
-        const float power = blend_power(r.at(2), r.at(4), r.at(3), dx, dy);
+    constexpr uint32_t kNoEntry = 0xFFFFFFFFu;
+    uint32_t last_e = kNoEntry;          // list entry of the pixel's last contributor in the current sub-chunk
+    auto consume = [&](const RowRec<C>& r, uint32_t entry) {
+        // blend_power(a2, b2, c2, dx, dy) with its subtractions and its first two products as PACKED operations on the record's
+        // register pairs (x, y) and (a2, c2) -- v_pk_add_f32 / v_pk_mul_f32: one issue slot for two results, and this walk is
+        // bound by vector issue.  Same operations, same roundings, same bits as blend_power() (ogs_common.h)
+        const v2f d = (v2f){r.at(0), r.at(1)} - (v2f){fxe, fy};
+        const v2f m = (v2f){r.at(2), r.at(3)} * d;                  // a2 * dx, c2 * dy
+        const float u = fmaf(r.at(4), d.y, m.x);                    // a2*dx + b2*dy
+        const float power = fmaf(m.y, d.y, u * d.x);
         const float h = r.at(5);
         const bool cand = fabsf(power + h) <= h;
         if (__ballot(cand) != 0ull) {
-            float alpha = fminf(0.99f, r.at(6) * __expf(power));
-            alpha = (cand && alpha >= kAlphaMin) ? alpha : 0.f;
+            const float araw = fminf(0.99f, r.at(6) * __expf(power));
+            const bool act = cand && araw >= kAlphaMin;
+            const float alpha = act ? araw : 0.f;
             const float test_T = T * (1.0f - alpha);
             const bool stop = test_T < 0.0001f;
             float w = alpha * T;
+            // the pixel's last contributor: this entry iff it contributes, w > 0 <=> act && !stop (alpha >= 1/255, T >= 1e-4).
+            // The condition is a lane mask the step already has (SGPR pair), and what is recorded is the step's LIST ENTRY as it
+            // sits in a VGPR (slot << 16 | LDS offset) -- one select per step; it becomes the stream index once per sub-chunk
+            // (`settle`), instead of an index add, a compare and a select per step
+            bool contributes = act;
             // a pixel saturates once: the three selects of the stop (weight, T, parking) only run in a step in which some lane
             // stops; every other step takes the values straight (same bits: the selects would have picked them)
             if (__ballot(stop) != 0ull) {
@@ -632,6 +653,7 @@ void pack_blend_chunked_kernel(
                 T = stop ? T : test_T;
                 fxe = stop ? kFar : fxe;
                 alive = __ballot(fxe < kFarTest);
+                contributes = act && !stop;
             } else {
                 T = test_T;
             }
@@ -640,7 +662,7 @@ void pack_blend_chunked_kernel(
             for (int k = 0; k < NPF; ++k)
                 accp[k] = __builtin_elementwise_fma((v2f){r.feat(2 * k), r.feat(2 * k + 1)}, w2, accp[k]);
             wacc += w;
-            last = w > 0.f ? jplus1 : last;
+            last_e = contributes ? entry : last_e;
         }
     };
 
@@ -774,11 +796,14 @@ void pack_blend_chunked_kernel(
             for (int t = 0; t < maxlen && alive != 0ull; t += 2) {
                 const uint32_t e2 = mylist[t + 2], e3 = mylist[t + 3];
                 rb.load_lds(rec_of(e1));
-                consume(ra, jbase + (e0 >> 16));
+                consume(ra, e0);
                 ra.load_lds(rec_of(e2));
-                if (t + 1 < maxlen) consume(rb, jbase + (e1 >> 16));
+                if (t + 1 < maxlen) consume(rb, e1);
                 e0 = e2; e1 = e3;
             }
+            // settle: list entry -> 1-based index into the quadrant stream (entry's slot in the sub-chunk + what came before)
+            if (last_e != kNoEntry) last = jbase + (last_e >> 16);
+            last_e = kNoEntry;
             __builtin_amdgcn_wave_barrier();
         }
 #pragma unroll
