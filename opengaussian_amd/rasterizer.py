@@ -443,8 +443,8 @@ class _RasterizeGaussians(torch.autograd.Function):
 # streams with the records' feature channels taken from the caller's current tensor (the kept records are never written).
 # Images, depth, alpha, radii and the feature gradients are bit for bit those of a full pass (tests/test_14_kept_pass_gpu.py).
 class _KeptPass:
-    __slots__ = ("key", "holds", "P", "W", "H", "Cn", "E", "fused", "D", "image", "sorted_rec", "quad_list", "radii", "nbytes",
-                 "hits", "full_binning")
+    __slots__ = ("key", "generation", "holds", "P", "W", "H", "Cn", "E", "fused", "D", "image", "sorted_rec", "quad_list", "radii",
+                 "nbytes", "hits", "full_binning")
 
 
 class KeptPasses:
@@ -457,7 +457,8 @@ class KeptPasses:
         self.budget_bytes = budget_bytes          # None: OGS_KEPT_PASSES_GB, default a quarter of the device's memory
         self.slots: dict = {}
         self.nbytes = 0
-        self.stats = {"hits": 0, "misses": 0, "stale": 0, "admitted": 0, "rejected_budget": 0}
+        self.stats = {"hits": 0, "misses": 0, "stale": 0, "admitted": 0, "rejected_budget": 0, "dropped_old_generation": 0,
+                      "rejected_out_of_memory": 0}
 
     def _budget(self, dev) -> int:
         if self.budget_bytes is None:
@@ -494,10 +495,13 @@ class KeptPasses:
         self.slots.clear()
         self.nbytes = 0
 
-    def admit(self, slot, key, holds, kept: dict) -> bool:
+    def admit(self, slot, key, holds, kept: dict, generation=None) -> bool:
         """kept: what _RasterizeGaussians.forward left in its keep_sink.  The record array and the quadrant streams of the pass
         were sized for a CAPACITY (1.25 x the recent maximum of num_rendered, and the reachable pairs are about half of it):
-        the used prefix is copied into exact-size buffers -- one 4-byte read-back per admitted view."""
+        the used prefix is copied into exact-size buffers -- one 4-byte read-back per admitted view.
+        generation: what all passes over ONE state of the model share (renderer.py: the parameters' part of the key).  Entries
+        of another generation can never hit again -- the model moved on, or another scene was loaded -- but cameras that are
+        not revisited would hold their bytes (and the old parameters) forever: when the budget is short they go first."""
         dev = kept["image"].device
         lib = _lib.lib()
         W, H, Cn = kept["W"], kept["H"], kept["Cn"]
@@ -510,17 +514,26 @@ class KeptPasses:
         if srb > kept["sorted_rec"].numel() or qlb > kept["quad_list"].numel():
             return False
         nbytes = srb + qlb + kept["image"].numel() + kept["radii"].numel() * 4
+        if self.nbytes + nbytes > self._budget(dev) and generation is not None:
+            for old_slot in [sl for sl, en in self.slots.items() if en.generation != generation]:
+                self.drop(old_slot)
+                self.stats["dropped_old_generation"] += 1
         if self.nbytes + nbytes > self._budget(dev):
             self.stats["rejected_budget"] += 1
             return False
         e = _KeptPass()
-        e.key, e.holds = key, holds
+        e.key, e.holds, e.generation = key, holds, generation
         e.P, e.W, e.H, e.Cn, e.fused, e.D = kept["P"], W, H, Cn, bool(kept["fused"]), used
         e.E = Cn - 3 if e.fused else Cn
         e.full_binning = kept["full_binning"]
         e.image, e.radii = kept["image"], kept["radii"]
-        e.sorted_rec = kept["sorted_rec"][:srb].clone()
-        e.quad_list = kept["quad_list"][:qlb].clone()
+        try:
+            e.sorted_rec = kept["sorted_rec"][:srb].clone()
+            e.quad_list = kept["quad_list"][:qlb].clone()
+        except torch.cuda.OutOfMemoryError:
+            # the budget is a share of the device, not of what the training process left free: keeping a pass is optional
+            self.stats["rejected_out_of_memory"] += 1
+            return False
         e.nbytes, e.hits = nbytes, 0
         self.drop(slot)
         self.slots[slot] = e
@@ -616,12 +629,13 @@ def rasterize_fused(means3D, means2D, opacities, shs, extra_feats, raster_settin
     depth / alpha outputs alone -- bit-for-bit what two separate reference passes (RGB with all gradients, feature
     pass with everything else detached) would accumulate.
 
-    frozen_key (extension): ``(slot, key, holds)`` -- the caller vouches that every input but `extra_feats` (and the
+    frozen_key (extension): ``(slot, key, holds[, generation])`` -- the caller vouches that every input but `extra_feats` (and the
     background) is the same whenever `key` is the same (renderer.py: storages + version counters of the model's parameters,
     the camera, the image size).  When none of those inputs requires grad, the first pass of a slot is kept (KEPT_PASSES,
     budget OGS_KEPT_PASSES_GB, 0 = off) and later passes with an equal key re-blend it: one launch instead of the
     whole binning pipeline, same bits.  `holds` (any object) is kept alive with the entry so that the addresses in `key`
-    cannot be recycled while it exists."""
+    cannot be recycled while it exists; `generation` (optional, hashable) names the model state the key belongs to: entries
+    of other generations are dropped first when the budget is short."""
     empty = torch.Tensor([])
     args = (means3D, means2D, shs, extra_feats, opacities, empty if scales is None else scales,
             empty if rotations is None else rotations, empty if cov3D_precomp is None else cov3D_precomp, raster_settings,
@@ -630,7 +644,8 @@ def rasterize_fused(means3D, means2D, opacities, shs, extra_feats, raster_settin
             (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in
                                              (means3D, means2D, opacities, shs, scales, rotations, cov3D_precomp))):
         return _RasterizeGaussians.apply(*args)
-    slot, key, holds = frozen_key
+    slot, key, holds = frozen_key[:3]
+    generation = frozen_key[3] if len(frozen_key) > 3 else None
     key = (key, bool(FULL_BINNING), int(extra_feats.shape[-1]))
     entry = KEPT_PASSES.lookup(slot, key)
     if entry is not None:
@@ -638,7 +653,7 @@ def rasterize_fused(means3D, means2D, opacities, shs, extra_feats, raster_settin
     sink: list = []
     out = _RasterizeGaussians.apply(*args, None, 1, sink)
     if sink:
-        KEPT_PASSES.admit(slot, key, holds, sink[0])
+        KEPT_PASSES.admit(slot, key, holds, sink[0], generation)
     return out
 
 

@@ -131,7 +131,7 @@ def _frozen_geometry_key(viewpoint_camera, pc, pipe, xyz, scaling_modifier):
            int(viewpoint_camera.image_width), float(viewpoint_camera.FoVx), float(viewpoint_camera.FoVy),
            float(scaling_modifier), int(pc.active_sh_degree))
     slot = (cam[0].data_ptr(), int(viewpoint_camera.image_height), int(viewpoint_camera.image_width))
-    return slot, key, (tuple(params), cam)
+    return slot, key, (tuple(params), cam), key[0]          # generation = the parameters' identities: one state of the model
 
 
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, iteration,

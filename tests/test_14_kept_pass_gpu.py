@@ -131,6 +131,19 @@ def test_changed_key_drops_the_entry_and_budget_stops_admission(kept, gpu_device
     R.KEPT_PASSES = R.KeptPasses(budget_bytes=1 << 16)
     _fused(R, sc, cam, f0, dev, ("cam1", ("v", 0), None))
     assert R.KEPT_PASSES.stats["rejected_budget"] == 1 and not R.KEPT_PASSES.slots
+    # ... except entries of another GENERATION of the model (they can never hit again): those go first
+    sc2, cam2, _, _ = _scene(dev, P=3000, seed=9)
+    one = R.KeptPasses(budget_bytes=4 << 30)
+    R.KEPT_PASSES = one
+    _fused(R, sc, cam, f0, dev, ("cam0", ("v", 0), None, "model-A"))
+    one.budget_bytes = one.nbytes + 1024                               # room for nothing more
+    _fused(R, sc2, cam2, sc2.ins_feat.to(dev), dev, ("cam1", ("v", 0), None, "model-A"))
+    assert one.stats["rejected_budget"] == 1 and list(one.slots) == ["cam0"]
+    one.budget_bytes = int(2.4 * one.nbytes)                           # room for one more of about the same size, not for two
+    _fused(R, sc2, cam2, sc2.ins_feat.to(dev), dev, ("cam1", ("v", 0), None, "model-A"))
+    assert sorted(one.slots) == ["cam0", "cam1"] and one.stats["admitted"] == 2
+    _fused(R, sc, cam, f0, dev, ("cam2", ("w", 0), None, "model-B"))
+    assert one.stats["dropped_old_generation"] == 2 and list(one.slots) == ["cam2"]
     R.KEPT_PASSES = R.KeptPasses(budget_bytes=0)                       # off
     _fused(R, sc, cam, f0, dev, ("cam1", ("v", 0), None))
     assert R.KEPT_PASSES.stats["misses"] == 0

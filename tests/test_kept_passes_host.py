@@ -9,9 +9,9 @@ from opengaussian_amd import rasterizer as R
 from opengaussian_amd.renderer import _frozen_geometry_key
 
 
-def _entry(key, nbytes):
+def _entry(key, nbytes, generation=None):
     e = R._KeptPass()
-    e.key, e.nbytes, e.hits = key, nbytes, 0
+    e.key, e.nbytes, e.hits, e.generation = key, nbytes, 0, generation
     return e
 
 
