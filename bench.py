@@ -92,6 +92,10 @@ WORKLOADS = {
     "C2-100k-800": dict(P=100_000, W=800, H=800, f=700.0),
     "C3-500k-988": dict(P=500_000, W=988, H=731, f=800.0),      # LeRF-teatime-class image and point count
     "C4-2M-648": dict(P=2_000_000, W=648, H=484, f=500.0),      # ScanNet-class: many Gaussians, small image
+    # the same model seen from INSIDE: three quarters of it behind the camera (a room-scale scan: a view sees a fraction of the
+    # model; the synthetic scenes above put every Gaussian in front of the camera).  Not a BASELINE.json config: an `extras`
+    # line for the per-Gaussian kernels and the depth sort, whose work should follow what is visible
+    "C4-2M-648-inside": dict(P=2_000_000, W=648, H=484, f=500.0, behind=0.75),
 }
 
 
@@ -352,7 +356,7 @@ def extra_workloads(args):
     (HIP events around every launch inflate sub-10-us kernels) and the HBM roofline of its dominant kernel."""
     import subprocess
     res = {}
-    for wl, key in (("C2-100k-800", "C2"), ("C3-500k-988", "C3"), ("C4-2M-648", "C4")):
+    for wl, key in (("C2-100k-800", "C2"), ("C3-500k-988", "C3"), ("C4-2M-648", "C4"), ("C4-2M-648-inside", "C4_inside")):
         log(f"extra workload {wl}")
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", wl, "--steps", "100", "--warmup", "10",
                "--views", str(args.views), "--no-cpu-baseline", "--no-kmeans", "--no-extra-workloads"]
@@ -438,6 +442,9 @@ def main():
     wl = WORKLOADS[args.workload]
     P, W, H, f = wl["P"], wl["W"], wl["H"], wl["f"]
     scene_cpu = make_scene(P, W, H, f, f, seed=0)
+    if wl.get("behind"):
+        gone = torch.rand(P, generator=torch.Generator().manual_seed(1234)) < wl["behind"]
+        scene_cpu.means3D[gone, 2] = -scene_cpu.means3D[gone, 2].abs() - 1.0
     log(f"scene built: P={P} {W}x{H}")
     # step i of rank r renders view (i * world + r) mod V of a fan of V cameras about the scene centre (view 0 = the
     # identity camera of SURVEY.md section 8(d)): every rank a different view every step, as in multi-view training

@@ -58,10 +58,13 @@ __device__ __forceinline__ void load_items(const uint32_t* __restrict__ in, cons
     }
 }
 
+// n_dev (optional, both scan kernels): the element count lives in device memory (the depth order holds only the Gaussians the
+// first pass of the depth sort kept); n is the capacity the launch is sized for, elements past the count are zeros
 __global__ __launch_bounds__(kBlock) void scan_reduce_kernel(const uint32_t* __restrict__ in,
                                                              const uint32_t* __restrict__ gather, int64_t n,
-                                                             uint32_t* __restrict__ partials) {
+                                                             uint32_t* __restrict__ partials, const uint32_t* __restrict__ n_dev) {
     __shared__ uint32_t wave_sums[4];
+    if (n_dev) n = min(n, (int64_t)*n_dev);
     const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
     uint32_t item[kScanItems];
     load_items(in, gather, base, n, item);
@@ -83,8 +86,9 @@ __global__ __launch_bounds__(kBlock) void scan_apply_kernel(const uint32_t* __re
                                                             const uint32_t* __restrict__ gather,
                                                             uint32_t* __restrict__ out, int64_t n,
                                                             const uint32_t* __restrict__ partial_offsets,
-                                                            uint32_t* __restrict__ total_out) {
+                                                            uint32_t* __restrict__ total_out, const uint32_t* __restrict__ n_dev) {
     __shared__ uint32_t wave_sums[4];
+    if (n_dev) n = min(n, (int64_t)*n_dev);
     const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
     uint32_t item[kScanItems];
     load_items(in, gather, base, n, item);
@@ -117,8 +121,11 @@ __global__ __launch_bounds__(kBlock) void scan_apply_kernel(const uint32_t* __re
 
 // grand total for the multi-level case: offset of the last block + its sum = exclusive[n-1] + in[n-1]
 __global__ void scan_total_kernel(const uint32_t* __restrict__ in, const uint32_t* __restrict__ gather,
-                                  const uint32_t* __restrict__ out, int64_t n, uint32_t* __restrict__ total_out) {
+                                  const uint32_t* __restrict__ out, int64_t n, uint32_t* __restrict__ total_out,
+                                  const uint32_t* __restrict__ n_dev) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (n_dev) n = min(n, (int64_t)*n_dev);
+        if (n <= 0) { *total_out = 0u; return; }
         const uint32_t last = gather ? in[gather[n - 1]] : in[n - 1];
         *total_out = out[n - 1] + last;
     }
@@ -634,7 +641,7 @@ int radix_sort_pass(int pass, int npass, const uint32_t* keys_in, const uint32_t
 }
 
 int exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int64_t n, uint32_t* total,
-                       void* tmp, hipStream_t stream, int debug) {
+                       void* tmp, hipStream_t stream, int debug, const uint32_t* n_dev) {
     if (n <= 0) {
         if (total) OGS_HIP_CHECK(hipMemsetAsync(total, 0, sizeof(uint32_t), stream));
         return OGS_OK;
@@ -642,29 +649,29 @@ int exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out
     const int nb = scan_blocks(n);
     if (nb == 1) {
         OGS_LAUNCH(scan_apply_kernel<false>, dim3(1), dim3(kBlock), 0, stream, in, gather, out, n,
-                           (const uint32_t*)nullptr, total);
+                           (const uint32_t*)nullptr, total, n_dev);
         OGS_LAUNCH_CHECK(debug, stream);
         return OGS_OK;
     }
     uint32_t* partials = static_cast<uint32_t*>(tmp);
     void* next_tmp = static_cast<char*>(tmp) + align_up((size_t)nb * sizeof(uint32_t));
-    OGS_LAUNCH(scan_reduce_kernel, dim3(nb), dim3(kBlock), 0, stream, in, gather, n, partials);
+    OGS_LAUNCH(scan_reduce_kernel, dim3(nb), dim3(kBlock), 0, stream, in, gather, n, partials, n_dev);
     OGS_LAUNCH_CHECK(debug, stream);
     if (nb <= kFlatScanBlocks) {
         // two launches: every workgroup sums the partials before it (<= 16 K values, L2 resident)
         OGS_LAUNCH(scan_apply_kernel<true>, dim3(nb), dim3(kBlock), 0, stream, in, gather, out, n,
-                           (const uint32_t*)partials, total);
+                           (const uint32_t*)partials, total, n_dev);
         OGS_LAUNCH_CHECK(debug, stream);
         return OGS_OK;
     }
-    int rc = exclusive_scan_u32(partials, nullptr, partials, nb, nullptr, next_tmp, stream, debug);
+    int rc = exclusive_scan_u32(partials, nullptr, partials, nb, nullptr, next_tmp, stream, debug, nullptr);
     if (rc != OGS_OK) return rc;
     OGS_LAUNCH(scan_apply_kernel<false>, dim3(nb), dim3(kBlock), 0, stream, in, gather, out, n,
-                       (const uint32_t*)partials, (uint32_t*)nullptr);
+                       (const uint32_t*)partials, (uint32_t*)nullptr, n_dev);
     OGS_LAUNCH_CHECK(debug, stream);
     if (total) {
         if (in == out) { set_error("exclusive_scan_u32: total with in-place scan unsupported"); return OGS_ERR_INVALID_ARG; }
-        OGS_LAUNCH(scan_total_kernel, dim3(1), dim3(64), 0, stream, in, gather, (const uint32_t*)out, n, total);
+        OGS_LAUNCH(scan_total_kernel, dim3(1), dim3(64), 0, stream, in, gather, (const uint32_t*)out, n, total, n_dev);
         OGS_LAUNCH_CHECK(debug, stream);
     }
     return OGS_OK;

@@ -232,21 +232,28 @@ int ogs_raster_forward_geometry(const OgsRasterFwdArgs* a, void* stream_, int64_
     } else {
         rc = launch_preprocess(*a, gs, gt, s);
         if (rc != OGS_OK) return rc;
-        // depth sort of the P Gaussians: 4 x 8-bit stable passes, ends in keys[0]/order[0]
+        // depth sort of the Gaussians that are drawn: 4 x 8-bit stable passes, ends in keys[0]/order[0].  A Gaussian that is
+        // not (behind the near plane, outside every group, degenerate, empty tile rect: preprocess gave it the key kDropKey)
+        // leaves the list in the FIRST pass -- the mechanism the tile sort uses for its unreachable pairs -- and the other
+        // three passes, the scan and duplicate run on the visible count (device word; the launches stay sized for P).  On the
+        // bench scene that is 14 % of the Gaussians; a camera inside a room-scale scene sees a fraction of the model
+        // (the reference only ever sorts the pairs of visible Gaussians: SURVEY.md Appendix A.2).
         const bool sweep = radix_onesweep_enabled(a->P);
         if (sweep) {
             const int shifts[4] = {0, 8, 16, 24}, nbits[4] = {8, 8, 8, 8};
-            rc = radix_sort_begin(gt.keys[0], a->P, nullptr, 4, shifts, nbits, gt.sort_tmp, s, a->debug);
+            rc = radix_sort_begin(gt.keys[0], a->P, nullptr, 4, shifts, nbits, gt.sort_tmp, s, a->debug, true);
             if (rc != OGS_OK) return rc;
         }
         for (int pass = 0; pass < 4; ++pass) {
             const int in = pass & 1, out = in ^ 1;
-            rc = sweep ? radix_sort_pass(pass, 4, gt.keys[in], gt.order[in], gt.keys[out], gt.order[out], a->P, 8 * pass, 8, gt.sort_tmp, s, a->debug)
-                       : radix_pass(gt.keys[in], gt.order[in], gt.keys[out], gt.order[out], a->P, 8 * pass, 8, gt.sort_tmp, s, a->debug);
+            const bool drop = pass == 0;
+            const uint32_t* n_pass = drop ? nullptr : gt.visible();
+            rc = sweep ? radix_sort_pass(pass, 4, gt.keys[in], gt.order[in], gt.keys[out], gt.order[out], a->P, 8 * pass, 8, gt.sort_tmp, s, a->debug, n_pass, drop, drop ? gt.visible() : nullptr)
+                       : radix_pass(gt.keys[in], gt.order[in], gt.keys[out], gt.order[out], a->P, 8 * pass, 8, gt.sort_tmp, s, a->debug, n_pass, drop, drop ? gt.visible() : nullptr);
             if (rc != OGS_OK) return rc;
         }
         // offsets[r] = exclusive scan of tiles_touched in depth order; total = num_rendered
-        rc = exclusive_scan_u32(gt.tiles_touched, gt.order[0], gt.offsets, a->P, gt.num_rendered, gt.sort_tmp, s, a->debug);
+        rc = exclusive_scan_u32(gt.tiles_touched, gt.order[0], gt.offsets, a->P, gt.num_rendered, gt.sort_tmp, s, a->debug, gt.visible());
         if (rc != OGS_OK) return rc;
     }
     if (num_rendered_host) {       // blocking read-back (what the reference does once per forward)

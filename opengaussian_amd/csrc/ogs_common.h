@@ -226,8 +226,10 @@ size_t sort_tmp_bytes(int64_t n);                      // histogram + scan scrat
 
 // exclusive prefix sum of n uint32 (in may equal out); if total != nullptr the grand total is
 // written there (device).  `gather` (optional) makes element i = in[gather[i]].
+// n_dev (optional): the element count lives in device memory, n is the capacity the launches are sized for; elements past the
+// count read as zeros and their outputs are not written.
 int exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, int64_t n,
-                       uint32_t* total, void* tmp, hipStream_t stream, int debug);
+                       uint32_t* total, void* tmp, hipStream_t stream, int debug, const uint32_t* n_dev = nullptr);
 // One-launch-per-pass variant (decoupled look-back): radix_sort_begin zeroes the scratch and histograms every digit of
 // the `npass` planned passes in one read of the keys; radix_sort_pass is pass `pass` of that plan (ONE launch).
 // radix_onesweep_enabled(n): false for n >= 2^30 or OGS_RADIX=legacy (then use radix_pass, three launches per pass).
@@ -254,8 +256,11 @@ struct GeomTmp {        // transient, but must survive from forward_geometry to 
     uint32_t* keys[2];         // [P] depth bits ping-pong
     uint32_t* order[2];        // [P] Gaussian ids ping-pong; order[0] holds the depth order at the end
     uint32_t* offsets;         // [P] exclusive scan of tiles_touched in depth order
-    uint32_t* num_rendered;    // [1]
+    uint32_t* num_rendered;    // [64] word 0: num_rendered; word 1 (`visible()`): Gaussians in the depth order -- the culled ones
+                               // (key kDropKey: behind the near plane, outside every group, empty tile rect) leave the depth
+                               // sort in its first pass, so the later passes, the scan and duplicate only see what is drawn
     void* sort_tmp;
+    uint32_t* visible() const { return num_rendered + 1; }
     static GeomTmp carve(void* p, int P) {
         Carver c(p);
         GeomTmp g;

@@ -357,14 +357,15 @@ __global__ __launch_bounds__(kSmallMaxP) void small_geometry_kernel(
         total += t;
     }
     if (idx < P) offsets[idx] = before + incl - v;
-    if (idx == 0) *num_rendered = total;
+    if (idx == 0) { num_rendered[0] = total; num_rendered[1] = (uint32_t)P; }     // word 1: entries of the depth order (GeomTmp::visible)
 }
 
 // Emit one (tile id, Gaussian id) pair per touched tile, Gaussians visited in DEPTH order so that a
 // stable sort by tile id alone reproduces the reference's (tile<<32 | depth_bits) order with ties
 // broken by Gaussian index (DESIGN.md "binning").
 template <int NV>
-__global__ __launch_bounds__(kBlock) void duplicate_kernel(int P, int W, int H, const float4* __restrict__ rec,
+__global__ __launch_bounds__(kBlock) void duplicate_kernel(int P_cap, const uint32_t* __restrict__ n_visible, int W, int H,
+                                                           const float4* __restrict__ rec,
                                                            const uint32_t* __restrict__ order,
                                                            const uint32_t* __restrict__ offsets,
                                                            uint32_t* __restrict__ tile_keys,
@@ -395,6 +396,10 @@ __global__ __launch_bounds__(kBlock) void duplicate_kernel(int P, int W, int H, 
     // the tile ranges start from zero (tile_ranges_kernel only writes the tiles that appear): cleared here, by a kernel that
     // runs before the sort anyway, instead of by a memset launch of its own
     if (zero_ranges != nullptr && r < n_zero) zero_ranges[r] = make_uint2(0u, 0u);
+    // the depth order holds the visible Gaussians only (capi.hip: the culled ones left the depth sort in its first pass); the
+    // launch is sized for all of them, workgroups past the count have nothing to emit
+    const int P = min(P_cap, (int)*n_visible);
+    if ((int)blockIdx.x * kBlock >= P) return;            // block-uniform
     const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
     uint32_t off = 0, cnt = 0, gid = 0, rect = 1u << 24, key0 = 0;
     float4 ctr = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -574,9 +579,9 @@ int launch_duplicate(const OgsRasterFwdArgs& a, const GeomState& gs, const GeomT
         return OGS_ERR_UNSUPPORTED;
     }
     switch (rec_vec4(a.C)) {
-        case 3: OGS_LAUNCH(duplicate_kernel<3>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals, capacity, grp, drop_unreachable, zero_ranges, n_zero); break;
-        case 4: OGS_LAUNCH(duplicate_kernel<4>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals, capacity, grp, drop_unreachable, zero_ranges, n_zero); break;
-        case 5: OGS_LAUNCH(duplicate_kernel<5>, dim3(grid), dim3(kBlock), 0, s, a.P, a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals, capacity, grp, drop_unreachable, zero_ranges, n_zero); break;
+        case 3: OGS_LAUNCH(duplicate_kernel<3>, dim3(grid), dim3(kBlock), 0, s, a.P, (const uint32_t*)gt.visible(), a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals, capacity, grp, drop_unreachable, zero_ranges, n_zero); break;
+        case 4: OGS_LAUNCH(duplicate_kernel<4>, dim3(grid), dim3(kBlock), 0, s, a.P, (const uint32_t*)gt.visible(), a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals, capacity, grp, drop_unreachable, zero_ranges, n_zero); break;
+        case 5: OGS_LAUNCH(duplicate_kernel<5>, dim3(grid), dim3(kBlock), 0, s, a.P, (const uint32_t*)gt.visible(), a.W, a.H, gs.rec, gt.order[0], gt.offsets, tile_keys, vals, capacity, grp, drop_unreachable, zero_ranges, n_zero); break;
         default: set_error("unsupported record size"); return OGS_ERR_UNSUPPORTED;
     }
     OGS_LAUNCH_CHECK(a.debug, s);

@@ -233,6 +233,45 @@ def test_backward_parity(gpu_device, use_sh, use_cov, seed):
         assert e < GRAD_TOL, f"{k}: relative error {e} (all: {errs})"
 
 
+@pytest.mark.parametrize("P,keep", [(6000, 0.2), (1500, 0.05), (3000, 0.0)])
+def test_view_that_culls_most_of_the_model(gpu_device, P, keep):
+    """A camera inside a room-scale scene sees a fraction of the model.  The culled Gaussians (behind the near plane, empty
+    tile rect) carry the drop key and leave the depth sort in its FIRST pass; the later passes, the scan of the tile counts
+    and duplicate run on the visible count (a device word), the launches stay sized for P.  Keys, point list, ranges, radii:
+    bit-exact against the oracle; images and every gradient at the usual bars -- with 80 %, 95 % and ALL of the model culled."""
+    from oracle import raster_oracle as ro
+    W, H, f = 144, 96, 110.0
+    sc, cam = helpers.tiny_scene(P, W, H, f, seed=17)
+    g = torch.Generator().manual_seed(3)
+    gone = torch.rand(P, generator=g) >= keep
+    # half of the culled ones behind the camera, the other half far off to the side (in front, empty tile rect)
+    behind = gone & (torch.rand(P, generator=g) < 0.5)
+    aside = gone & ~behind
+    sc.means3D[behind, 2] = -sc.means3D[behind, 2].abs() - 1.0
+    sc.means3D[aside, 0] = sc.means3D[aside, 0] + 500.0
+    inp = helpers.oracle_inputs(sc, cam)
+    bg = (0.1, 0.2, 0.3)
+    ref = ro.render_forward(W=W, H=H, tanfovx=W / (2 * f), tanfovy=H / (2 * f), bg=np.array(bg, np.float32), sh_degree=3, **inp)
+    (color, radii, depth, alpha), leaves = helpers.hip_forward(inp, cam, bg, 3, gpu_device, requires_grad=True)
+    gm, b = ref["geom"], ref["binning"]
+    np.testing.assert_array_equal(radii.cpu().numpy(), gm.radii)
+    visible = int((gm.radii > 0).sum())
+    assert visible <= max(1, int(1.3 * keep * P)) and (keep == 0.0) == (visible == 0)
+    if visible:
+        keys, ranges, ncontrib, plist = helpers.hip_export_binning(color)
+        assert len(keys) == b.num_rendered
+        np.testing.assert_array_equal(keys, b.keys_sorted)
+        np.testing.assert_array_equal(plist, b.point_list)
+        np.testing.assert_array_equal(ranges, b.ranges)
+    np.testing.assert_allclose(color.detach().cpu().numpy(), ref["color"], atol=IMG_TOL, rtol=0)
+    np.testing.assert_allclose(alpha.detach().cpu().numpy(), ref["alpha"], atol=IMG_TOL, rtol=0)
+    if visible:
+        errs = _grad_check(inp, cam, W, H, f, gpu_device, seed=4)
+        assert errs
+        for k, e in errs.items():
+            assert e < GRAD_TOL, f"{k}: relative error {e} (all: {errs})"
+
+
 def test_backward_parity_6ch(gpu_device):
     """fused 6-channel ins_feat pass (colors_precomp [P,6]) forward + backward."""
     W, H, f = 96, 64, 80.0
