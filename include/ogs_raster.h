@@ -240,6 +240,20 @@ int ogs_raster_forward_tiny(const OgsRasterFwdArgs* args, void* stream);
  * forward.  Asynchronous. */
 int ogs_raster_forward_reblend(const OgsRasterFwdArgs* args, void* stream);
 
+/* Compaction of the state a pass leaves behind, for a caller that keeps it (ogs_raster_forward_reblend).  The pass lays its
+ * record array and quadrant streams out by the tile ranges of the sorted list -- tile t owns n_t = ranges[t].y - ranges[t].x slots
+ * -- and packs only the k_t <= n_t records its pixels needed before every one of them was saturated (k_t = word 4 of the tile's
+ * five counters in image_buffer; 15 % of the list on a ScanNet-class view).  The caller copies image_buffer, overwrites the
+ * ranges at its start with new_ranges[t] = (exclusive scan of k, + k_t) -- image_buffer layout: uint2 ranges[tiles] first, then,
+ * each 256-byte aligned, u32 n_contrib[W*H], u32 counters[tiles][5], float final_T[W*H], u32 tile_order[tiles] -- and this call
+ * moves the k_t records and the four quadrant streams of every tile to the new offsets in buffers of
+ * ogs_raster_sorted_bytes(sum k, C) / ogs_raster_quad_list_bytes(sum k).  The new triple (image, records, streams) is what
+ * ogs_raster_forward_reblend and the features-only ogs_raster_backward take; ogs_raster_export_binning does not apply to it.
+ * Asynchronous. */
+int ogs_raster_compact_kept(int32_t W, int32_t H, int32_t C, const void* image_buffer, const void* sorted_rec,
+                            const void* quad_list, void* new_image_buffer, void* new_sorted_rec, void* new_quad_list,
+                            void* stream);
+
 /* Backward.  Asynchronous on `stream`.  In the features-only case (see OgsRasterBwdArgs) only P, W, H, C, num_rendered,
  * num_groups, radii, dL_dcolor, image_buffer, sorted_rec, quad_list, bwd_tmp, dL_dcolors are read, `colors_precomp` and `shs`
  * are only tested against NULL (shs != NULL: fused SH pass, dL_dcolors is [P, C-3]); the other inputs, geom_buffer and

@@ -82,6 +82,7 @@ SIGNATURES = {
     "ogs_raster_tiny_max_points": (C.c_size_t, []),
     "ogs_raster_forward_tiny": (C.c_int, [C.POINTER(OgsRasterFwdArgs), _vp]),
     "ogs_raster_forward_reblend": (C.c_int, [C.POINTER(OgsRasterFwdArgs), _vp]),
+    "ogs_raster_compact_kept": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ogs_mark_visible": (C.c_int, [C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "ogs_sh_grad_from_views": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "ogs_raster_export_binning": (C.c_int, [C.POINTER(OgsRasterFwdArgs), C.c_int64, _vp, _vp, _vp, _vp]),

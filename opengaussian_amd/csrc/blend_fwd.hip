@@ -1186,6 +1186,44 @@ int reblend_c(const OgsRasterFwdArgs& a, const ImageState& is, hipStream_t s) {
     return OGS_OK;
 }
 
+// Compaction of a pass that is going to be kept (rasterizer.KeptPasses): the pass' record array and quadrant streams are laid out
+// by the tile ranges of the SORTED list (tile t at range.x, capacity n_t = its list length), but a tile only ever packed the
+// k_t <= n_t records its pixels needed (qcount[t][4]: 15 % of the list on a ScanNet-class view, where the workgroups leave early).
+// One workgroup per tile copies the k_t records and the four quadrant streams to the offsets of the NEW ranges (exclusive scan of
+// k_t, built by the caller): 6 x less to keep for such a view.  The fifth region of the stream block (positions in the full
+// list, read by the n_contrib export only) is not carried over.
+template <int C>
+__global__ __launch_bounds__(kBlock) void compact_kept_kernel(const uint2* __restrict__ old_ranges, const uint2* __restrict__ new_ranges,
+                                                              const uint32_t* __restrict__ qcount, const float4* __restrict__ old_rec,
+                                                              const uint32_t* __restrict__ old_quad, float4* __restrict__ new_rec,
+                                                              uint32_t* __restrict__ new_quad) {
+    constexpr int SV = stream_vec4(C);
+    const int tile = blockIdx.x;
+    const uint2 ro = old_ranges[tile], rn = new_ranges[tile];
+    const uint32_t n_old = ro.y - ro.x, k = qcount[tile * 5 + 4];
+    const float4* __restrict__ src = old_rec + (size_t)ro.x * SV;
+    float4* __restrict__ dst = new_rec + (size_t)rn.x * SV;
+    for (uint32_t e = threadIdx.x; e < k * SV; e += kBlock) dst[e] = src[e];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t nq = qcount[tile * 5 + q];
+        const uint32_t* __restrict__ qs = old_quad + ((size_t)ro.x * 5 + (size_t)q * n_old);
+        uint32_t* __restrict__ qd = new_quad + ((size_t)rn.x * 5 + (size_t)q * k);
+        for (uint32_t e = threadIdx.x; e < nq; e += kBlock) qd[e] = qs[e];
+    }
+}
+
+template <int C>
+int compact_c(int W, int H, const ImageState& is_old, const ImageState& is_new, const void* old_rec, const void* old_quad,
+              void* new_rec, void* new_quad, hipStream_t s) {
+    const int gx = (W + kTile - 1) / kTile, gy = (H + kTile - 1) / kTile;
+    OGS_LAUNCH(compact_kept_kernel<C>, dim3((unsigned)(gx * gy)), dim3(kBlock), 0, s, (const uint2*)is_old.ranges,
+               (const uint2*)is_new.ranges, (const uint32_t*)is_old.qcount, (const float4*)stream_base<C>(const_cast<void*>(old_rec)),
+               (const uint32_t*)quad_base(const_cast<void*>(old_quad)), stream_base<C>(new_rec), quad_base(new_quad));
+    OGS_LAUNCH_CHECK(0, s);
+    return OGS_OK;
+}
+
 template <int C>
 int export_c(const OgsRasterFwdArgs& a, const ImageState& is, uint32_t* out, hipStream_t s) {
     const int gx = (a.W + kTile - 1) / kTile, gy = (a.H + kTile - 1) / kTile;
@@ -1228,6 +1266,17 @@ int launch_blend_forward(const OgsRasterFwdArgs& a, const GeomState& gs, const I
         case 9: return launch_c<9>(a, gs, is, D, s);
         case 12: return launch_c<12>(a, gs, is, D, s);
         default: set_error("unsupported channel count C=%d", a.C); return OGS_ERR_UNSUPPORTED;
+    }
+}
+
+int launch_compact_kept(int W, int H, int C, const ImageState& is_old, const ImageState& is_new, const void* old_rec,
+                        const void* old_quad, void* new_rec, void* new_quad, hipStream_t s) {
+    switch (C) {
+        case 3: return compact_c<3>(W, H, is_old, is_new, old_rec, old_quad, new_rec, new_quad, s);
+        case 6: return compact_c<6>(W, H, is_old, is_new, old_rec, old_quad, new_rec, new_quad, s);
+        case 9: return compact_c<9>(W, H, is_old, is_new, old_rec, old_quad, new_rec, new_quad, s);
+        case 12: return compact_c<12>(W, H, is_old, is_new, old_rec, old_quad, new_rec, new_quad, s);
+        default: set_error("unsupported channel count C=%d", C); return OGS_ERR_UNSUPPORTED;
     }
 }
 

@@ -373,6 +373,18 @@ int ogs_raster_forward_reblend(const OgsRasterFwdArgs* a, void* stream_) {
     return launch_reblend(*a, is, static_cast<hipStream_t>(stream_));
 }
 
+int ogs_raster_compact_kept(int32_t W, int32_t H, int32_t C, const void* image_buffer, const void* sorted_rec, const void* quad_list,
+                            void* new_image_buffer, void* new_sorted_rec, void* new_quad_list, void* stream_) {
+    if (W <= 0 || H <= 0) { set_error("compact_kept: bad sizes W=%d H=%d", W, H); return OGS_ERR_INVALID_ARG; }
+    if (!image_buffer || !sorted_rec || !quad_list || !new_image_buffer || !new_sorted_rec || !new_quad_list) {
+        set_error("compact_kept: NULL pointer"); return OGS_ERR_INVALID_ARG;
+    }
+    const ImageState is_old = ImageState::carve(const_cast<void*>(image_buffer), W, H, 1);
+    const ImageState is_new = ImageState::carve(new_image_buffer, W, H, 1);
+    return launch_compact_kept(W, H, C, is_old, is_new, sorted_rec, quad_list, new_sorted_rec, new_quad_list,
+                               static_cast<hipStream_t>(stream_));
+}
+
 size_t ogs_raster_tiny_max_points(void) { return (size_t)kTinyMaxP; }
 
 int ogs_raster_forward_tiny(const OgsRasterFwdArgs* a, void* stream_) {

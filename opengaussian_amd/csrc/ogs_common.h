@@ -314,6 +314,9 @@ int launch_small_geometry(const OgsRasterFwdArgs& a, const GeomState& gs, const 
 int launch_tiny_blend(const OgsRasterFwdArgs& a, const GeomState& gs, const uint32_t* order, hipStream_t s);
 // re-blend of a kept pass with new feature channels (blend_fwd.hip::refresh_features_kernel + the stand-alone forward blend)
 int launch_reblend(const OgsRasterFwdArgs& a, const ImageState& is, hipStream_t s);
+// a finished pass' records and quadrant streams re-laid out by the ranges of what each tile packed (blend_fwd.hip)
+int launch_compact_kept(int W, int H, int C, const ImageState& is_old, const ImageState& is_new, const void* old_rec,
+                        const void* old_quad, void* new_rec, void* new_quad, hipStream_t s);
 // zero_ranges / n_zero (optional, n_zero <= P): the kernel also clears that many tile ranges (then launch_tile_ranges is told so)
 int launch_duplicate(const OgsRasterFwdArgs& a, const GeomState& gs, const GeomTmp& gt, uint32_t* tile_keys,
                      uint32_t* vals, uint32_t capacity, bool drop_unreachable, hipStream_t s, uint2* zero_ranges = nullptr,

@@ -438,8 +438,8 @@ class _RasterizeGaussians(torch.autograd.Function):
 # entry for entry, the binning state of the previous one -- preprocess, both sorts, the duplication and pack are spent on
 # reproducing bytes that already exist.  With 288 GB of HBM they can simply stay: a finished pass whose caller vouches for its
 # geometry (`frozen_key`, renderer.py builds it from the parameters' storages and version counters) leaves image_buffer, the
-# compacted records, the quadrant streams and the radii behind (~0.35 GB for a 1080p view of 1 M Gaussians, exact size after a
-# prefix copy), and the next pass with the same key is ogs_raster_forward_reblend: ONE launch, the forward blend over the kept
+# packed records, their quadrant streams and the radii behind (~0.3 GB for a 1080p view of 1 M Gaussians, 0.1 GB for a ScanNet-class
+# view whose tiles stop at 15 % of their lists: compacted to what the tiles packed), and the next pass with the same key is ogs_raster_forward_reblend: ONE launch, the forward blend over the kept
 # streams with the records' feature channels taken from the caller's current tensor (the kept records are never written).
 # Images, depth, alpha, radii and the feature gradients are bit for bit those of a full pass (tests/test_14_kept_pass_gpu.py).
 class _KeptPass:
@@ -497,8 +497,9 @@ class KeptPasses:
 
     def admit(self, slot, key, holds, kept: dict, generation=None) -> bool:
         """kept: what _RasterizeGaussians.forward left in its keep_sink.  The record array and the quadrant streams of the pass
-        were sized for a CAPACITY (1.25 x the recent maximum of num_rendered, and the reachable pairs are about half of it):
-        the used prefix is copied into exact-size buffers -- one 4-byte read-back per admitted view.
+        were sized for a CAPACITY (1.25 x the recent maximum of num_rendered, and the reachable pairs are about half of it) and
+        laid out by the sorted list's tile ranges: the records and stream entries the tiles actually PACKED are moved into
+        exact-size buffers (ogs_raster_compact_kept) -- one 8-byte read-back per admitted view.
         generation: what all passes over ONE state of the model share (renderer.py: the parameters' part of the key).  Entries
         of another generation can never hit again -- the model moved on, or another scene was loaded -- but cameras that are
         not revisited would hold their bytes (and the old parameters) forever: when the budget is short they go first."""
@@ -506,14 +507,17 @@ class KeptPasses:
         lib = _lib.lib()
         W, H, Cn = kept["W"], kept["H"], kept["Cn"]
         tiles = ((W + 15) // 16) * ((H + 15) // 16)
-        ranges = kept["image"][: tiles * 8].view(torch.int32).view(tiles, 2)
-        used = int(ranges[:, 1].max().item())                # entries of the (culled) sorted list
+        image = kept["image"]
+        # image_buffer layout (include/ogs_raster.h, ogs_raster_compact_kept): ranges | n_contrib | counters | final_T | tile_order
+        up = lambda n: (n + 255) // 256 * 256
+        o_cnt = up(tiles * 8) + up(W * H * 4)
+        packed = image[o_cnt:o_cnt + tiles * 20].view(torch.int32).view(tiles, 5)[:, 4].to(torch.int64)   # records per tile
+        ends = torch.cumsum(packed, 0)
+        used = int(ends[-1].item())                           # the one read-back of an admission
         if used <= 0:
             return False
         srb, qlb = int(lib.ogs_raster_sorted_bytes(used, Cn)), int(lib.ogs_raster_quad_list_bytes(used))
-        if srb > kept["sorted_rec"].numel() or qlb > kept["quad_list"].numel():
-            return False
-        nbytes = srb + qlb + kept["image"].numel() + kept["radii"].numel() * 4
+        nbytes = srb + qlb + image.numel() + kept["radii"].numel() * 4
         if self.nbytes + nbytes > self._budget(dev) and generation is not None:
             for old_slot in [sl for sl, en in self.slots.items() if en.generation != generation]:
                 self.drop(old_slot)
@@ -526,14 +530,21 @@ class KeptPasses:
         e.P, e.W, e.H, e.Cn, e.fused, e.D = kept["P"], W, H, Cn, bool(kept["fused"]), used
         e.E = Cn - 3 if e.fused else Cn
         e.full_binning = kept["full_binning"]
-        e.image, e.radii = kept["image"], kept["radii"]
+        e.radii = kept["radii"]
         try:
-            e.sorted_rec = kept["sorted_rec"][:srb].clone()
-            e.quad_list = kept["quad_list"][:qlb].clone()
+            # the pass laid its records and quadrant streams out by the ranges of the sorted list, sized for a capacity; what is
+            # kept is what the tiles PACKED (all a re-blend reads), re-laid out by the exclusive scan of those counts
+            e.image = image.clone()
+            new_ranges = torch.stack((ends - packed, ends), 1).to(torch.int32).contiguous()
+            e.image[: tiles * 8] = new_ranges.view(-1).view(torch.uint8)
+            e.sorted_rec = torch.empty(srb, dtype=torch.uint8, device=dev)
+            e.quad_list = torch.empty(qlb, dtype=torch.uint8, device=dev)
         except torch.cuda.OutOfMemoryError:
             # the budget is a share of the device, not of what the training process left free: keeping a pass is optional
             self.stats["rejected_out_of_memory"] += 1
             return False
+        check(lib.ogs_raster_compact_kept(W, H, Cn, ptr(image), ptr(kept["sorted_rec"]), ptr(kept["quad_list"]), ptr(e.image),
+                                          ptr(e.sorted_rec), ptr(e.quad_list), _stream()), "ogs_raster_compact_kept")
         e.nbytes, e.hits = nbytes, 0
         self.drop(slot)
         self.slots[slot] = e

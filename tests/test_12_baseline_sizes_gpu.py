@@ -133,3 +133,48 @@ def test_baseline_config_forward_and_backward_vs_oracle(gpu_device, name):
         errs[k] = helpers.assert_grads_close_modulo_threshold_flips(gk, w, GRAD_TOL, want_fp32=lambda k=k: want32()[k],
                                                                     what=f"{name} {k}")
     print(name + ": " + ", ".join(f"{k}={e:.2e}" for k, e in errs.items()))
+
+
+@pytest.mark.parametrize("name", ["C4", "S1M"])
+def test_kept_pass_at_full_size_is_bit_identical(gpu_device, name):
+    """The frozen-geometry re-blend (rasterizer.KeptPasses, ogs_raster_forward_reblend) at the sizes BASELINE.json names: at
+    C4-class the chunked forward leaves its lists after ~15 % (the kept streams end where the workgroups left them), at S1M
+    the lists run to their end.  Same features -> the images of the pass that was kept; new features -> the images of a full
+    pass; feature gradients of the re-blend = those of the full pass' features-only backward."""
+    from opengaussian_amd import rasterizer as R
+    P, W, H, f, _fused, _n = CONFIGS[name]
+    dev = gpu_device
+    sc = make_scene(P, W, H, f, f, seed=0).to(dev)
+    cam = make_camera(W, H, f, f).to(dev)
+    rs = helpers.settings_for(cam, (0.0, 0.0, 0.0), 3, dev)
+    g = torch.Generator().manual_seed(9)
+    f1 = torch.rand(P, 6, generator=g).to(dev)
+    gC = torch.randn(9, H, W, generator=g).to(dev)
+    m2 = torch.zeros(P, 3, device=dev)
+
+    def run(feats, key):
+        leaf = feats.clone().requires_grad_(True)
+        out = R.rasterize_fused(sc.means3D, m2, sc.opacities, sc.shs, leaf, rs, scales=sc.scales, rotations=sc.rotations,
+                                frozen_key=key)
+        (out[0] * gC).sum().backward()
+        return out, leaf.grad
+
+    saved, R.KEPT_PASSES = R.KEPT_PASSES, R.KeptPasses(budget_bytes=8 << 30)
+    try:
+        key = ("view0", "frozen", None)
+        n0 = R.PASS_STATS["reblend"]
+        miss, _ = run(sc.ins_feat, key)
+        hit, _ = run(sc.ins_feat, key)
+        new, g_new = run(f1, key)
+        assert R.PASS_STATS["reblend"] == n0 + 2 and R.KEPT_PASSES.stats["admitted"] == 1
+        full, g_full = run(f1, None)
+        for a, b, what in zip(miss, hit, ("color", "radii", "depth", "alpha")):
+            assert torch.equal(a, b), (name, "same features", what)
+        for a, b, what in zip(full, new, ("color", "radii", "depth", "alpha")):
+            assert torch.equal(a, b), (name, "new features", what)
+        scale = float(g_full.abs().max())
+        assert scale > 0 and float((g_new - g_full).abs().max()) <= 1e-6 * scale
+        e = next(iter(R.KEPT_PASSES.slots.values()))
+        print(name, "kept bytes per view", e.nbytes, "entries", e.D)
+    finally:
+        R.KEPT_PASSES = saved

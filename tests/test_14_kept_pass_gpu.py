@@ -81,7 +81,7 @@ def test_reblend_is_bit_identical_to_a_full_pass(kept, gpu_device):
     assert R.PASS_STATS["reblend"] == before + 2
     for a, b, what in zip(full, again, ("color", "radii", "depth", "alpha")):
         assert torch.equal(a, b), what
-    # and the kept entry is exact-size: the record array holds the used prefix only
+    # and the kept entry is exact-size: the record array holds what the tiles packed, nothing else
     e = next(iter(R.KEPT_PASSES.slots.values()))
     assert e.sorted_rec.numel() == int(R._lib.lib().ogs_raster_sorted_bytes(e.D, 9)) and e.nbytes == R.KEPT_PASSES.nbytes
 
