@@ -556,6 +556,71 @@ class KeptPasses:
 KEPT_PASSES = KeptPasses()
 
 
+class KeptImages:
+    """Outputs of a pass in which NOTHING trains: stage >= 1 renders RGB from frozen parameters on every call (the unfused RGB pass
+    of the rescaled stage-2.1 calls, gaussian_renderer/__init__.py:104-112, and every stage-2.2 call, train.py:339-341) -- for a
+    given camera, model state and background tensor the same image, depth, alpha and radii, bit for bit, every time.  45 MB per
+    1080p view.  Same slots / keys / generations / budget rules as KeptPasses; a hit hands out CLONES (callers may modify what
+    they get)."""
+
+    def __init__(self, budget_bytes=None):
+        self.budget_bytes = budget_bytes          # None: the budget of KEPT_PASSES (counted separately)
+        self.slots: dict = {}
+        self.nbytes = 0
+        self.stats = {"hits": 0, "misses": 0, "stale": 0, "admitted": 0, "rejected_budget": 0}
+
+    def _budget(self, dev) -> int:
+        return KEPT_PASSES._budget(dev) if self.budget_bytes is None else self.budget_bytes
+
+    def lookup(self, slot, key):
+        e = self.slots.get(slot)
+        if e is None or e[0] != key:
+            if e is not None:
+                self.drop(slot)
+                self.stats["stale"] += 1
+            self.stats["misses"] += 1
+            return None
+        self.stats["hits"] += 1
+        return tuple(t.clone() for t in e[3])
+
+    def drop(self, slot):
+        e = self.slots.pop(slot, None)
+        if e is not None:
+            self.nbytes -= e[4]
+
+    def clear(self):
+        self.slots.clear()
+        self.nbytes = 0
+
+    def admit(self, slot, key, holds, outputs, generation=None) -> bool:
+        dev = outputs[0].device
+        nbytes = sum(t.numel() * t.element_size() for t in outputs)
+        if self.nbytes + nbytes > self._budget(dev) and generation is not None:
+            for old_slot in [sl for sl, en in self.slots.items() if en[1] != generation]:
+                self.drop(old_slot)
+        if self.nbytes + nbytes > self._budget(dev):
+            self.stats["rejected_budget"] += 1
+            return False
+        try:
+            kept = tuple(t.detach().clone() for t in outputs)
+        except torch.cuda.OutOfMemoryError:
+            return False
+        self.drop(slot)
+        self.slots[slot] = (key, generation, holds, kept, nbytes)
+        self.nbytes += nbytes
+        self.stats["admitted"] += 1
+        return True
+
+
+KEPT_IMAGES = KeptImages()
+
+
+def clear_kept():
+    """Forget every kept pass and kept image (after parameter values were written behind torch's back: `.data`, raw pointers)."""
+    KEPT_PASSES.clear()
+    KEPT_IMAGES.clear()
+
+
 class _ReblendKept(torch.autograd.Function):
     """forward: ogs_raster_forward_reblend on a kept pass; backward: the features-only ogs_raster_backward on the same state."""
 

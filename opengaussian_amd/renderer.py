@@ -21,6 +21,7 @@ import math
 
 import torch
 
+from . import rasterizer as _rasterizer
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_fused, rasterize_groups
 
 # a grouped pass materialises [G, C+2, H, W] fp32: bound G per pass (the loop over passes keeps the order)
@@ -110,7 +111,7 @@ def _frozen_geometry_key(viewpoint_camera, pc, pipe, xyz, scaling_modifier):
     step, `reset_opacity`, densification's `cat` -- bumps the counter or moves the storage; `.detach()`, which train.py repeats
     every iteration, does neither), the camera's matrices likewise, and the scalar settings of the pass.  The tensors are held
     by the entry, so an address cannot be handed out again while its key is in use.  NOT covered: writes through `.data` or
-    raw pointers (they leave the counter alone) -- call ``rasterizer.KEPT_PASSES.clear()`` after such a write, or set
+    raw pointers (they leave the counter alone) -- call ``rasterizer.clear_kept()`` after such a write, or set
     OGS_KEPT_PASSES_GB=0.  Returns None when the model does not look like the reference's GaussianModel (no such attributes,
     `get_xyz` not the `_xyz` parameter itself), when anything still requires grad, or under `pipe.debug`."""
     if getattr(pipe, "debug", False) or getattr(pipe, "compute_cov3D_python", False) or getattr(pipe, "convert_SHs_python", False):
@@ -228,9 +229,24 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, iteration,
         silhouette = rendered_alpha
     else:
         if render_color:
-            rendered_image, radii, rendered_depth, rendered_alpha = rasterizer(
-                means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
-                scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+            # nothing of this pass trains once the model is frozen (the unfused RGB pass of a rescaled stage-2.1 call, every
+            # stage-2.2 call): for a camera, a model state and a background tensor its outputs are the same every time
+            frozen = None
+            if shs is not None and not viewspace_grad and scales is not None and xyz.is_cuda and _rasterizer.KEPT_PASSES.enabled(dev):
+                frozen = _frozen_geometry_key(viewpoint_camera, pc, pipe, xyz, scaling_modifier)
+            hit = None
+            if frozen is not None:
+                img_key = (frozen[1], bg_color.data_ptr(), bg_color._version, tuple(bg_color.shape))
+                hit = _rasterizer.KEPT_IMAGES.lookup(frozen[0], img_key)
+            if hit is not None:
+                rendered_image, radii, rendered_depth, rendered_alpha = hit
+            else:
+                rendered_image, radii, rendered_depth, rendered_alpha = rasterizer(
+                    means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
+                    scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+                if frozen is not None and not rendered_image.requires_grad:
+                    _rasterizer.KEPT_IMAGES.admit(frozen[0], img_key, (frozen[2], bg_color),
+                                      (rendered_image, radii, rendered_depth, rendered_alpha), frozen[3])
         if render_feat_map:
             # `scales * rescale_factor` with scales=None (compute_cov3D_python) raises, as in the reference (:135)
             if ins_feat.shape[-1] in (3, 6, 9, 12) and ins_feat.shape[-1] <= max_pass_channels:

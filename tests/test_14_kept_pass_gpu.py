@@ -206,3 +206,52 @@ def test_render_keeps_the_stage1_pass_and_invalidates_on_a_parameter_update(kept
     for _ in range(6):
         render(cam, pc, pipe, bg, iteration=60000, rescale=True)
     assert R.PASS_STATS["reblend"] - n == plain    # exactly the calls whose draw came out as "no rescale"
+
+
+def test_render_keeps_the_outputs_of_a_pass_in_which_nothing_trains(kept, gpu_device):
+    """Stage 2.2 (train.py:339-341: render_feat=False, render_cluster=True) and the rescaled calls of stage 2.1 render RGB through
+    the unfused pass from frozen parameters: for a camera, a model state and a background tensor the same outputs every time.
+    The second call returns them from rasterizer.KEPT_IMAGES -- bit for bit, as fresh tensors -- without launching a pass; another
+    background tensor, a parameter update or a model that still trains -> a real pass."""
+    from opengaussian_amd.renderer import render
+    R, dev = kept, gpu_device
+    saved, R.KEPT_IMAGES = R.KEPT_IMAGES, R.KeptImages(budget_bytes=1 << 30)
+    try:
+        sc, cam, W, H = _scene(dev, P=5000, seed=13)
+        pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=False)
+        bg = torch.tensor([0.2, 0.1, 0.3], device=dev)
+        pc = ReferenceShapedGaussians(sc, dev)
+        passes = lambda: sum(R.PASS_STATS[k] for k in ("blocking", "deferred", "tiny", "reblend"))
+        call = lambda b=bg: render(cam, pc, pipe, b, iteration=60000, rescale=False, render_feat_map=False)
+        n0 = passes()
+        a = call()
+        assert passes() == n0 + 1 and R.KEPT_IMAGES.stats["admitted"] == 1 and a["ins_feat"] is None
+        b = call()
+        assert passes() == n0 + 1 and R.KEPT_IMAGES.stats["hits"] == 1               # no pass was launched
+        for k in ("render", "alpha", "depth", "radii", "visibility_filter"):
+            assert torch.equal(a[k], b[k]), k
+            assert a[k].data_ptr() != b[k].data_ptr()                               # clones: the caller may write into them
+        b["render"].zero_()
+        c = call()
+        assert torch.equal(c["render"], a["render"]) and passes() == n0 + 1
+        # another background TENSOR (random_background draws a new one per iteration): a real pass, and the right image
+        bg2 = torch.tensor([0.9, 0.8, 0.0], device=dev)
+        d = call(bg2)
+        assert passes() == n0 + 2 and not torch.equal(d["render"], a["render"])
+        R.KEPT_IMAGES, on = R.KeptImages(budget_bytes=0), R.KEPT_IMAGES
+        ref = call(bg2)
+        R.KEPT_IMAGES = on
+        assert torch.equal(ref["render"], d["render"]) and torch.equal(call(bg2)["render"], ref["render"])
+        # a parameter update invalidates
+        with torch.no_grad():
+            pc._opacity.add_(0.3)
+        n1 = passes()
+        e = call()
+        assert passes() == n1 + 1 and not torch.equal(e["render"], a["render"])
+        # a model that still trains never goes through the cache
+        pc._xyz = pc._xyz.clone().requires_grad_(True)
+        n2, hits = passes(), R.KEPT_IMAGES.stats["hits"]
+        call(); call()
+        assert passes() == n2 + 2 and R.KEPT_IMAGES.stats["hits"] == hits
+    finally:
+        R.KEPT_IMAGES = saved
