@@ -658,8 +658,12 @@ __global__ __launch_bounds__(kBlock) void blend_backward_feat_lds_kernel(
     float4* __restrict__ recs = s_rec[wave];
 
     auto consume = [&](const float4& r0, const float4& r1, int idx) {
-        const float dx = r0.x - fx, dy = r0.y - fy;
-        const float power = blend_power(r0.z, r1.x, r0.w, dx, dy);
+        // blend_power() with its subtractions and first two products packed (v_pk_add_f32 / v_pk_mul_f32 on the record's
+        // register pairs (x, y), (-A/2, -C/2)): same operations, same roundings, same bits -- two issue slots less per step
+        const v2f d = (v2f){r0.x, r0.y} - (v2f){fx, fy};
+        const v2f m = (v2f){r0.z, r0.w} * d;
+        const float u = fmaf(r1.x, d.y, m.x);
+        const float power = fmaf(m.y, d.y, u * d.x);
         const float hh = r1.y;
         const bool near = fabsf(power + hh) <= hh, reached = idx < last_contrib;
         const bool cand = near && reached;
