@@ -438,9 +438,10 @@ class _RasterizeGaussians(torch.autograd.Function):
 # entry for entry, the binning state of the previous one -- preprocess, both sorts, the duplication and pack are spent on
 # reproducing bytes that already exist.  With 288 GB of HBM they can simply stay: a finished pass whose caller vouches for its
 # geometry (`frozen_key`, renderer.py builds it from the parameters' storages and version counters) leaves image_buffer, the
-# packed records, their quadrant streams and the radii behind (~0.3 GB for a 1080p view of 1 M Gaussians, 0.1 GB for a ScanNet-class
-# view whose tiles stop at 15 % of their lists: compacted to what the tiles packed), and the next pass with the same key is ogs_raster_forward_reblend: ONE launch, the forward blend over the kept
-# streams with the records' feature channels taken from the caller's current tensor (the kept records are never written).
+# packed records, their quadrant streams and the radii behind (0.35 GB for a 1080p view of 1 M Gaussians, 0.08 GB for a
+# ScanNet-class view whose tiles stop at 15 % of their lists: compacted to what the tiles packed), and the next pass with the same
+# key is ogs_raster_forward_reblend: ONE launch, the forward blend over the kept streams with the records' feature channels taken
+# from the caller's current tensor (the kept records are never written).
 # Images, depth, alpha, radii and the feature gradients are bit for bit those of a full pass (tests/test_14_kept_pass_gpu.py).
 class _KeptPass:
     __slots__ = ("key", "generation", "holds", "P", "W", "H", "Cn", "E", "fused", "D", "image", "sorted_rec", "quad_list", "radii",
