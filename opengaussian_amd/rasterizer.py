@@ -455,7 +455,7 @@ class KeptPasses:
     once the working set exceeds the budget, while a fixed resident subset keeps hitting for its share of the views."""
 
     def __init__(self, budget_bytes=None):
-        self.budget_bytes = budget_bytes          # None: OGS_KEPT_PASSES_GB, default a quarter of the device's memory
+        self.budget_bytes = budget_bytes          # None: OGS_KEPT_PASSES_GB, default min(device / 4, free / 2) at first use
         self.slots: dict = {}
         self.nbytes = 0
         self.stats = {"hits": 0, "misses": 0, "stale": 0, "admitted": 0, "rejected_budget": 0, "dropped_old_generation": 0,
@@ -467,7 +467,10 @@ class KeptPasses:
             if env is not None:
                 self.budget_bytes = int(float(env) * (1 << 30))
             else:
-                self.budget_bytes = int(torch.cuda.get_device_properties(dev).total_memory) // 4
+                # a quarter of the device, but never more than half of what is free when the first pass asks: the cache must not
+                # be what pushes the training process into an out-of-memory error
+                free, total = torch.cuda.mem_get_info(dev)
+                self.budget_bytes = int(min(total // 4, free // 2))
         return self.budget_bytes
 
     def enabled(self, dev) -> bool:
