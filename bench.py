@@ -349,6 +349,49 @@ def stage1_bench(leaves, all_settings, gF, P, device, reps=40):
     return out
 
 
+def frozen_rgb_bench(scene, cams, W, H, device, reps=32):
+    """A call in which nothing trains (every stage-2.2 iteration, train.py:339-341; the RGB pass of a rescaled stage-2.1 call):
+    `renderer.render(..., render_feat_map=False)` over a model shaped like scene/gaussian_model.py:GaussianModel with every
+    parameter detached -- first through the full pipeline (cache off), then with rasterizer.KeptImages (the drop-in default)."""
+    import types
+    from opengaussian_amd import rasterizer as R
+    from opengaussian_amd.renderer import render
+    shs = scene.shs.detach()
+    pc = types.SimpleNamespace(
+        _xyz=scene.means3D.detach(), _scaling=torch.log(scene.scales.detach()), _rotation=scene.rotations.detach(),
+        _opacity=torch.logit(scene.opacities.detach().clamp(1e-6, 1 - 1e-6)), _features_dc=shs[:, :1].contiguous(),
+        _features_rest=shs[:, 1:].contiguous(), _ins_feat=scene.ins_feat.detach(), active_sh_degree=3, max_sh_degree=3)
+    pc.get_xyz = pc._xyz
+    pc.get_scaling, pc.get_rotation, pc.get_opacity, pc.get_features = scene.scales.detach(), pc._rotation, scene.opacities.detach(), shs
+    pc.get_ins_feat = lambda origin=False: pc._ins_feat
+    pipe = types.SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=False)
+    bg = torch.zeros(3, device=device)
+    cams = [c.to(device) for c in cams]
+
+    def timed():
+        for i in range(len(cams)):
+            render(cams[i], pc, pipe, bg, 60000, rescale=False, render_feat_map=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(reps):
+            render(cams[i % len(cams)], pc, pipe, bg, 60000, rescale=False, render_feat_map=False)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    saved = R.KEPT_IMAGES
+    try:
+        R.KEPT_IMAGES = R.KeptImages(budget_bytes=0)
+        full = timed()
+        R.KEPT_IMAGES = R.KeptImages(budget_bytes=4 << 30)
+        kept = timed()
+        st, nbytes = dict(R.KEPT_IMAGES.stats), R.KEPT_IMAGES.nbytes // max(len(R.KEPT_IMAGES.slots), 1)
+    finally:
+        R.KEPT_IMAGES = saved
+    return {"ms_per_call_full_pass": full, "ms_per_call_kept_outputs": kept, "kept_bytes_per_view": nbytes, "cache": st,
+            "what": "render(render_feat_map=False) of a fully detached model, 3-channel SH pass, forward only; kept: the "
+                    "call returns clones of the camera's kept image / depth / alpha / radii, no pass is launched"}
+
+
 def extra_workloads(args):
     """The other single-GPU configurations of BASELINE.json (C2 100 k / 800x800, C3-class 500 k / 988x731, C4-class 2 M /
     648x484), same fused 9-channel fwd+bwd step: each is a CHILD run of this script (fresh process, this process keeps its
@@ -935,6 +978,10 @@ def main():
                 out["stage1_pass"] = stage1_bench(leaves, all_settings, gF, P, device)
             except Exception as e:
                 out["stage1_pass"] = {"error": repr(e)}
+            try:
+                out["frozen_rgb_call"] = frozen_rgb_bench(scene, cams_cpu, W, H, device)
+            except Exception as e:
+                out["frozen_rgb_call"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline (oracle)")
             out["cpu_baseline"] = cpu_baseline(scene_cpu, cam_cpu, W, H, f, args.cpu_tile_stride, args.rgb_only)
