@@ -166,7 +166,11 @@ struct RankOneFold {
 //      loop invariant, split once per kernel into two planes of 8 VGPRs (the 16 VGPRs the fp32 operand took); the moment
 //      basis (values k/4, |.| <= 12.25) is exact in ONE bf16 term.  Product error <= 2^-15 |w g| (q likewise), unbiased:
 //      measured against the float64 oracle in tests/test_10 / test_12 (same 2e-4 bar as before).
-//      OGS_BLEND_FOLD=f32 keeps the exact-fp32 product (alternative-kernel test).
+//      NOT the default any more (end of round 4): the kernel is bound by the atomic path, the two products time the same
+//      (0.617 / 0.626 against 0.620 / 0.620 ms, A-B on one box) -- and a randomised soak (scripts/fuzz_parity.py) found what
+//      2^-15 per product costs when a Gaussian's sum cancels: a one-Gaussian scene of 20 pixels with dL/dopacity 3.5e-4 off
+//      (every seeded test scales errors by the maximum over many Gaussians).  The exact-fp32 product is the default;
+//      OGS_BLEND_FOLD=bf16 selects this one (alternative-kernel test, A-B timing).
 //  (b) the moments leave the wave about a GLOBAL origin -- the image's pixel (0, 0) -- instead of the Gaussian's own
 //      centre: with X = x0 + u (x0 the quadrant centre) every record slot is  own + cA m0 + cB mu + cC mv  with three
 //      per-LANE constants that do not depend on the entry (slot MX: cA = x0; MXX: cA = x0^2, cB = 2 x0; MXY: cA = x0 y0,
@@ -714,7 +718,7 @@ static bool feat_lds_enabled() {
 }
 
 static bool fold_bf16_enabled() {
-    static const bool v = [] { const char* e = getenv("OGS_BLEND_FOLD"); return !(e && strcmp(e, "f32") == 0); }();
+    static const bool v = [] { const char* e = getenv("OGS_BLEND_FOLD"); return e && strcmp(e, "bf16") == 0; }();
     return v;
 }
 
@@ -754,8 +758,8 @@ int launch_c(const OgsRasterBwdArgs& a, const ImageState& is, void* grad_rec_, h
         OGS_LAUNCH_CHECK(a.debug, s);
         return OGS_OK;
     }
-    // the fold's product: two-term bf16 split on v_mfma_f32_16x16x32_bf16 (default) or, OGS_BLEND_FOLD=f32, exact fp32 on
-    // v_mfma_f32_16x16x4_f32 (round 2 / 3; kept for the alternative-kernel parity test and A-B timing)
+    // the fold's product: exact fp32 on v_mfma_f32_16x16x4_f32 (default) or, OGS_BLEND_FOLD=bf16, a two-term bf16 split on
+    // v_mfma_f32_16x16x32_bf16 (round 4 a; kept for the alternative-kernel parity test and A-B timing)
     const bool bf16 = fold_bf16_enabled();
 #define OGS_BWD_LAUNCH(GCV, DEPTHV)                                                                                  \
     if (bf16)                                                                                                        \
