@@ -46,3 +46,27 @@ def test_frozen_key_is_refused_unless_the_model_is_frozen_and_reference_shaped()
     pc._opacity = torch.zeros(4, 1, requires_grad=True)        # still training: stage 0
     assert _frozen_geometry_key(cam, pc, pipe, pc._xyz, 1.0) is None
     assert _frozen_geometry_key(cam, pc, types.SimpleNamespace(debug=True), pc._xyz, 1.0) is None
+
+
+def test_kept_images_hand_out_clones_and_follow_the_same_slot_rules():
+    ki = R.KeptImages(budget_bytes=1 << 20)
+    outs = (torch.arange(12.0).reshape(3, 2, 2), torch.tensor([3, 0, 5], dtype=torch.int32), torch.ones(1, 2, 2), torch.zeros(1, 2, 2))
+    assert ki.lookup("cam0", "k0") is None and ki.stats["misses"] == 1
+    assert ki.admit("cam0", "k0", holds=None, outputs=outs, generation="A")
+    outs[0].zero_()                                            # the caller keeps working on what it got: the kept copy must not move
+    hit = ki.lookup("cam0", "k0")
+    assert hit is not None and torch.equal(hit[0], torch.arange(12.0).reshape(3, 2, 2)) and hit[1].dtype == torch.int32
+    hit[0].fill_(7.0)                                          # ... and neither on what a hit handed out
+    assert torch.equal(ki.lookup("cam0", "k0")[0], torch.arange(12.0).reshape(3, 2, 2)) and ki.stats["hits"] == 2
+    nbytes = ki.nbytes
+    assert nbytes == 12 * 4 + 3 * 4 + 4 * 4 + 4 * 4
+    assert ki.lookup("cam0", "k1") is None and ki.stats["stale"] == 1 and ki.nbytes == 0       # another key: dropped
+    # budget: entries of an older generation go first, then admission stops
+    ki = R.KeptImages(budget_bytes=2 * nbytes + 8)
+    fresh = lambda: tuple(t.clone() for t in (torch.arange(12.0).reshape(3, 2, 2), torch.tensor([3, 0, 5], dtype=torch.int32),
+                                              torch.ones(1, 2, 2), torch.zeros(1, 2, 2)))
+    assert ki.admit("cam0", "k", None, fresh(), "A") and ki.admit("cam1", "k", None, fresh(), "A")
+    assert not ki.admit("cam2", "k", None, fresh(), "A") and ki.stats["rejected_budget"] == 1 and len(ki.slots) == 2
+    assert ki.admit("cam2", "k", None, fresh(), "B") and list(ki.slots) == ["cam2"] and ki.nbytes == nbytes
+    ki.clear()
+    assert not ki.slots and ki.nbytes == 0
