@@ -413,6 +413,8 @@ def extra_workloads(args):
                         "roofline": d["roofline"], "step_algorithmic_GBps": d["step_algorithmic_GBps"],
                         "kernels_ms_per_step": d["kernels_ms_per_step"],
                         "stage1_ms_per_step": (d.get("stage1_pass") or {}).get("ms_per_step"),
+                        "stage1_kept_pass_ms_per_step": ((d.get("stage1_pass") or {}).get("kept_pass") or {}).get("ms_per_step"),
+                        "kept_bytes_per_view": ((d.get("stage1_pass") or {}).get("kept_pass") or {}).get("kept_bytes_per_view"),
                         "render_phase_sizing_timed": d["render_phase_sizing_timed"]}
         except Exception as e:          # an extra line never takes the headline down
             res[key] = {"error": repr(e)}
