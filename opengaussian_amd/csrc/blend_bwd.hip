@@ -534,7 +534,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_feat_kernel(
     int H, int gx, int tiles, const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ qcount,
     const float* __restrict__ dL_dcolor, ACC* __restrict__ grad_rec, int pf_lines, const uint32_t* __restrict__ tile_order) {
     constexpr int RS = stream_vec4(C) * 4;
-    constexpr int GS = grad_stride(C);
+    constexpr int GS = feat_grad_stride(C, F0);
     constexpr int NS = C - F0;
     static_assert(NS >= 1 && NS <= 9, "feature slots");
     __shared__ WaveFoldLds s_fold[kBlock / kWave];
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(kBlock) void blend_backward_feat_lds_kernel(
     int H, int gx, int tiles, const uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ qcount,
     const float* __restrict__ dL_dcolor, ACC* __restrict__ grad_rec, int pf_lines, const uint32_t* __restrict__ tile_order) {
     constexpr int RS = stream_vec4(C) * 4;
-    constexpr int GS = grad_stride(C);
+    constexpr int GS = feat_grad_stride(C, F0);
     constexpr int NS = C - F0;
     static_assert(NS >= 1 && NS <= 9, "feature slots");
     __shared__ WaveFoldLds s_fold[kBlock / kWave];

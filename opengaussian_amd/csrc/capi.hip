@@ -429,9 +429,10 @@ int ogs_raster_backward(const OgsRasterBwdArgs* a, void* stream_) {
     if (a->num_groups < 0) { set_error("backward: num_groups=%d", a->num_groups); return OGS_ERR_INVALID_ARG; }
     const ImageState is = ImageState::carve(const_cast<void*>(a->image_buffer), a->W, a->H, num_groups_of(a->num_groups));
     void* grad_rec = a->bwd_tmp;
-    // (features-only pass: only the first 64-byte half of a record is used, but a strided hipMemset2DAsync of the halves cost
-    // 0.1 ms against 0.016 ms for this contiguous fill: measured, round 4)
-    OGS_HIP_CHECK(hipMemsetAsync(grad_rec, 0, (size_t)a->P * grad_stride(a->C) * sizeof(double), s));
+    // features-only pass: a record is the feature sums alone, 64 bytes when they fit (feat_grad_stride) -- half the fill.  (A strided
+    // hipMemset2DAsync over the front halves of full-size records cost 0.1 ms against 0.016 ms for a contiguous fill: measured.)
+    const int rec_doubles = feat_only ? feat_grad_stride(a->C, a->shs ? 3 : 0) : grad_stride(a->C);
+    OGS_HIP_CHECK(hipMemsetAsync(grad_rec, 0, (size_t)a->P * rec_doubles * sizeof(double), s));
     if (a->num_rendered > 0 && (!a->sorted_rec || !a->quad_list)) { set_error("backward: sorted_rec / quad_list == NULL"); return OGS_ERR_INVALID_ARG; }
     int rc = launch_blend_backward(*a, is, grad_rec, s);
     if (rc != OGS_OK) return rc;

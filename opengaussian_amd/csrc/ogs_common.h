@@ -149,6 +149,9 @@ struct StreamRec {
 // Features-only backward (blend_backward_feat_kernel): channels F0..C-1 sit at slots 0..C-F0-1 (first half only).
 constexpr int kSlotDepth = 9, kSlotMoments = 10;
 __host__ __device__ constexpr int grad_stride(int C) { return (C + 7 <= 16) ? 16 : 32; }
+// features-only backward: the record of a Gaussian is its NS = C - F0 feature sums alone -- one 64-byte segment when they fit
+// (half the bytes to clear before the pass and to read after it), the full stride otherwise
+__host__ __device__ constexpr int feat_grad_stride(int C, int F0) { return (C - F0 <= 8) ? 8 : grad_stride(C); }
 
 // ---- geometry scratch layout (shared by forward phases) ------------------------------------------
 struct GeomState {      // kept until backward

@@ -55,9 +55,11 @@ __global__ __launch_bounds__(kBlock) void preprocess_backward_kernel(
     // once, here
     double g64[16];
     {
-        const double2* g2 = reinterpret_cast<const double2*>(grad_rec + (size_t)idx * GS);
-        // features-only pass: the blend kernel only wrote the C - coff feature slots at the front of the record
-        const int npairs = feat_only_layout ? (C - (shs != nullptr ? 3 : 0) + 1) / 2 : 8;
+        // features-only pass: the record holds the C - coff feature sums alone, at its own stride (ogs_common.h::feat_grad_stride)
+        const int f0 = shs != nullptr ? 3 : 0;
+        const int gs = feat_only_layout ? feat_grad_stride(C, f0) : GS;
+        const double2* g2 = reinterpret_cast<const double2*>(grad_rec + (size_t)idx * gs);
+        const int npairs = feat_only_layout ? (C - f0 + 1) / 2 : 8;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const double2 t = (vis && k < npairs) ? g2[k] : make_double2(0.0, 0.0);
