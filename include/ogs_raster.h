@@ -151,7 +151,8 @@ typedef struct OgsRasterBwdArgs {
                                     kernels address the record array with 32-bit element offsets): P < 2^28 = 268 M Gaussians,
                                     larger P is rejected with OGS_ERR_UNSUPPORTED.  Holds the per-Gaussian gradient
                                     record, 16 fp64 running sums = 128 B (float atomics arrive in a different order every
-                                    run; an fp64 sum is order-insensitive to ~1e-16 and is rounded to fp32 once). */
+                                    run; an fp64 sum is order-insensitive to ~1e-16 and is rounded to fp32 once).  A features-only
+                                    pass uses the first P * 64 bytes only: a record is then the <= 8 feature sums alone. */
     float* dL_dmeans2D;          /* [P,3] (x,y in NDC units: pixel gradient * 0.5*W / 0.5*H; z = 0) */
     float* dL_dcolors;           /* same shape as colors_precomp: [P,C], or [P,C-3] in a fused SH pass */
     float* dL_dopacity;          /* [P] */
